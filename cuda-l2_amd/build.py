@@ -1,0 +1,149 @@
+"""Build driver for the MI355X HGEMM library (hipcc, gfx950 only).
+
+Replaces the reference's JIT path (tools/utils.py:39-107: torch cpp_extension.load with nvcc flags
+and the CUTLASS include) with explicit, content-hash-cached hipcc invocations:
+
+  csrc/*.hip                      -> lib/libhgemm_mi355x.so   (C ABI, include/hgemm_mi355x.h)
+  csrc/tools/hgemm_tune.cpp       -> bin/hgemm_tune           (native autotuner / micro-bench)
+  pybind/hgemm_mi355x_<acc>.cc    -> objects cached under build/ (linked per shape by tools/utils.py)
+
+Objects are cached under build/obj keyed by the hash of (command line, source, every header in
+csrc/ and include/), so a 1000-shape sweep compiles each distinct source once.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = REPO_DIR / "include"
+BUILD = PKG_DIR / "build"
+OBJ = BUILD / "obj"
+LIB_DIR = PKG_DIR / "lib"
+BIN_DIR = PKG_DIR / "bin"
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+HIPCC = str(ROCM / "bin" / "hipcc")
+ARCH = "gfx950"
+
+LIB_SOURCES = [
+    "hgemm_inst_g0.hip",
+    "hgemm_inst_g1.hip",
+    "hgemm_inst_g2.hip",
+    "hgemm_inst_g3.hip",
+    "hgemm_registry.hip",
+    "hgemm_api.hip",
+    "hgemm_baselines.hip",
+]
+
+HIP_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-Wno-unused-result", "-Wno-unused-value", "-DROCBLAS_NO_DEPRECATED_WARNINGS", "-D__HIP_PLATFORM_AMD__"]
+
+
+def _headers_digest() -> str:
+    h = hashlib.sha256()
+    for d in (CSRC, INCLUDE):
+        for p in sorted(d.rglob("*")):
+            if p.suffix in (".hpp", ".h", ".def", ".inc"):
+                h.update(p.name.encode())
+                h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _run(cmd: list[str], verbose: bool) -> None:
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError(f"build step failed ({res.returncode}): {' '.join(cmd)}")
+    if verbose and (res.stdout or res.stderr):
+        print(res.stdout + res.stderr, flush=True)
+
+
+def compile_object(src: Path, extra_flags: list[str], hdr_digest: str, verbose: bool = False) -> Path:
+    """hipcc -c one source into the object cache; returns the object path."""
+    OBJ.mkdir(parents=True, exist_ok=True)
+    cmd_core = [HIPCC, *HIP_FLAGS, *extra_flags, f"-I{CSRC}", f"-I{INCLUDE}", "-c"]
+    key = hashlib.sha256()
+    key.update(" ".join(cmd_core).encode())
+    key.update(hdr_digest.encode())
+    key.update(src.read_bytes())
+    obj = OBJ / f"{src.stem}-{key.hexdigest()[:20]}.o"
+    if not obj.exists():
+        tmp = obj.with_suffix(f".tmp{os.getpid()}.o")
+        _run([*cmd_core, str(src), "-o", str(tmp)], verbose)
+        os.replace(tmp, obj)
+    return obj
+
+
+def build_library(verbose: bool = False, jobs: int | None = None) -> Path:
+    """Build (or reuse) lib/libhgemm_mi355x.so and return its path."""
+    hdr = _headers_digest()
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    srcs = [CSRC / s for s in LIB_SOURCES]
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: compile_object(s, [], hdr, verbose), srcs))
+    LIB_DIR.mkdir(exist_ok=True)
+    lib = LIB_DIR / "libhgemm_mi355x.so"
+    stamp = LIB_DIR / ".libhgemm_mi355x.stamp"
+    want = hashlib.sha256(" ".join(o.name for o in objs).encode()).hexdigest()
+    if lib.exists() and stamp.exists() and stamp.read_text() == want:
+        return lib
+    tmp = lib.with_suffix(f".tmp{os.getpid()}.so")
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *map(str, objs), "-o", str(tmp),
+          f"-L{ROCM / 'lib'}", "-lrocblas", "-lhipblaslt", "-lamdhip64",
+          "-Wl,--no-undefined", "-Wl,-soname,libhgemm_mi355x.so"], verbose)
+    os.replace(tmp, lib)
+    stamp.write_text(want)
+    return lib
+
+
+def build_tools(verbose: bool = False) -> list[Path]:
+    """Native tools linked against the library (no torch): tuner / micro-benchmark."""
+    lib = build_library(verbose)
+    hdr = _headers_digest()
+    BIN_DIR.mkdir(exist_ok=True)
+    out = []
+    for name in ("hgemm_tune",):
+        src = CSRC / "tools" / f"{name}.cpp"
+        if not src.exists():
+            continue
+        obj = compile_object(src, ["-x", "hip"], hdr, verbose)
+        exe = BIN_DIR / name
+        stamp = BIN_DIR / f".{name}.stamp"
+        want = obj.name + lib.name + str(lib.stat().st_mtime_ns)
+        if not (exe.exists() and stamp.exists() and stamp.read_text() == want):
+            _run([HIPCC, f"--offload-arch={ARCH}", str(obj), "-o", str(exe), f"-L{LIB_DIR}", "-lhgemm_mi355x",
+                  f"-L{ROCM / 'lib'}", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}"],
+                 verbose)
+            stamp.write_text(want)
+        out.append(exe)
+    return out
+
+
+def clean() -> None:
+    for d in (BUILD, LIB_DIR, BIN_DIR):
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--clean", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--tools", action="store_true", help="also build bin/hgemm_tune")
+    a = ap.parse_args()
+    if a.clean:
+        clean()
+    print(build_library(a.verbose))
+    if a.tools:
+        for t in build_tools(a.verbose):
+            print(t)

@@ -1,0 +1,389 @@
+// Vendor baselines behind the C ABI: rocBLAS rocblas_gemm_ex, hipBLASLt heuristic, hipBLASLt
+// autotune.  They stand where the reference has cuBLAS / cuBLASLt
+// (cublas/{fp16,fp32}/hgemm_cublas.cu, hgemm_cublaslt_heuristic.cu, hgemm_cublaslt_auto_tuning.cu)
+// and follow the same protocol so that "speedup vs baseline" means the same thing:
+//   * row-major C = A.B is issued as the column-major product C^T = B^T.A^T
+//     (NN: B as [N x K] ld N, A as [K x M] ld K; TN: b_col_major as op(T) with ld K);
+//   * heuristic = top-1 of 4 requested, cached per problem;
+//   * autotune  = up to 100 heuristic candidates, 50 warm-up + 100 timed rounds, candidate order
+//     shuffled every round, fresh N(0,1) operands every round, median per candidate.
+// Differences, on purpose: the workspace is an explicit size_t (the reference's heuristic path
+// overflows `20 * 1024 * 1024 * 1024` to 0, hgemm_cublaslt_heuristic.cu:18), and the autotune is
+// time-boxed for very large shapes (HGEMM_AUTOTUNE_MAX_SECONDS, default 30 s per layout).
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include "../../include/hgemm_mi355x.h"
+
+namespace {
+
+typedef _Float16 f16;
+
+constexpr size_t kLtWorkspaceBytes = (size_t)256 << 20;  // 256 MiB, explicit size_t
+
+// ---------------------------------------------------------------------------------------------
+// N(0,1) fp16 fill: counter-based (splitmix64 -> Box-Muller), 2 values per 64-bit draw.
+__device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256) fill_normal_f16_kernel(f16* out, size_t n, uint64_t seed) {
+  const size_t pairs = (n + 1) / 2;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs;
+       p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t r = splitmix64(seed ^ splitmix64(p));
+    const float u1 = ((uint32_t)(r >> 32) + 1.0f) * (1.0f / 4294967296.0f);  // (0,1]
+    const float u2 = (uint32_t)r * (1.0f / 4294967296.0f);
+    const float rad = sqrtf(-2.0f * __logf(u1));
+    float s, c;
+    __sincosf(6.283185307179586f * u2, &s, &c);
+    out[2 * p] = (f16)(rad * c);
+    if (2 * p + 1 < n) out[2 * p + 1] = (f16)(rad * s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+rocblas_handle g_rocblas = nullptr;
+
+int rocblas_run(bool tn, const void* a, const void* b, void* c, int M, int N, int K, int acc,
+                void* stream) {
+  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
+  if (!g_rocblas) {
+    int st = hgemm_rocblas_init();
+    if (st != HGEMM_OK) return st;
+  }
+  if (rocblas_set_stream(g_rocblas, (hipStream_t)stream) != rocblas_status_success)
+    return HGEMM_ERR_BACKEND;
+  const float alpha32 = 1.0f, beta32 = 0.0f;
+  const f16 alpha16 = (f16)1.0f, beta16 = (f16)0.0f;
+  const bool h = (acc == HGEMM_ACC_FP16);
+  const void* alpha = h ? (const void*)&alpha16 : (const void*)&alpha32;
+  const void* beta  = h ? (const void*)&beta16 : (const void*)&beta32;
+  const rocblas_datatype ct = h ? rocblas_datatype_f16_r : rocblas_datatype_f32_r;
+  rocblas_status rs = rocblas_gemm_ex(
+      g_rocblas, tn ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none,
+      N, M, K, alpha, b, rocblas_datatype_f16_r, tn ? K : N, a, rocblas_datatype_f16_r, K, beta, c,
+      rocblas_datatype_f16_r, N, c, rocblas_datatype_f16_r, N, ct, rocblas_gemm_algo_standard, 0, 0);
+  return rs == rocblas_status_success ? HGEMM_OK : HGEMM_ERR_BACKEND;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One hipBLASLt problem (layout x shape x compute type) with its descriptors and chosen algo.
+struct LtProblem {
+  hipblasLtMatmulDesc_t   op = nullptr;
+  hipblasLtMatrixLayout_t a_desc = nullptr, b_desc = nullptr, c_desc = nullptr;
+  hipblasLtMatmulAlgo_t   algo;
+  size_t ws_needed = 0;
+  bool   have_algo = false;
+  int M = 0, N = 0, K = 0, acc = -1;
+  bool tn = false;
+  bool compute16 = false;   // descriptors built with HIPBLAS_COMPUTE_16F (alpha/beta are fp16 then)
+  int  candidates = 0;
+  double best_ms = 0.0;
+
+  void destroy() {
+    if (op) hipblasLtMatmulDescDestroy(op);
+    if (a_desc) hipblasLtMatrixLayoutDestroy(a_desc);
+    if (b_desc) hipblasLtMatrixLayoutDestroy(b_desc);
+    if (c_desc) hipblasLtMatrixLayoutDestroy(c_desc);
+    op = nullptr; a_desc = b_desc = c_desc = nullptr;   // nulled, unlike the reference (:51-60)
+    have_algo = false; acc = -1; M = N = K = 0;
+  }
+  bool matches(bool tn_, int M_, int N_, int K_, int acc_) const {
+    return op && tn == tn_ && M == M_ && N == N_ && K == K_ && acc == acc_;
+  }
+};
+
+struct LtContext {
+  hipblasLtHandle_t handle = nullptr;
+  void* workspace = nullptr;
+  LtProblem nn, tn;
+};
+
+LtContext g_heur, g_auto;
+
+int lt_init(LtContext& ctx) {
+  if (ctx.handle) return HGEMM_OK;
+  if (hipblasLtCreate(&ctx.handle) != HIPBLAS_STATUS_SUCCESS) {
+    ctx.handle = nullptr;
+    return HGEMM_ERR_BACKEND;
+  }
+  if (hipMalloc(&ctx.workspace, kLtWorkspaceBytes) != hipSuccess) {
+    hipblasLtDestroy(ctx.handle);
+    ctx.handle = nullptr; ctx.workspace = nullptr;
+    return HGEMM_ERR_HIP;
+  }
+  return HGEMM_OK;
+}
+
+int lt_destroy(LtContext& ctx) {
+  ctx.nn.destroy();
+  ctx.tn.destroy();
+  if (ctx.handle) hipblasLtDestroy(ctx.handle);
+  if (ctx.workspace) hipFree(ctx.workspace);
+  ctx.handle = nullptr; ctx.workspace = nullptr;
+  return HGEMM_OK;
+}
+
+// Build descriptors for the column-major product C^T[N x M] = op(B')[N x K] * A^T[K x M].
+int lt_describe(LtProblem& p, bool tn, int M, int N, int K, int acc, hipblasComputeType_t compute) {
+  p.destroy();
+  const hipDataType scale = (compute == HIPBLAS_COMPUTE_16F) ? HIP_R_16F : HIP_R_32F;
+  if (hipblasLtMatmulDescCreate(&p.op, compute, scale) != HIPBLAS_STATUS_SUCCESS) return HGEMM_ERR_BACKEND;
+  const hipblasOperation_t opa = tn ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = HIPBLAS_OP_N;
+  hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa));
+  hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb));
+  hipblasStatus_t s1 = tn ? hipblasLtMatrixLayoutCreate(&p.b_desc, HIP_R_16F, K, N, K)
+                          : hipblasLtMatrixLayoutCreate(&p.b_desc, HIP_R_16F, N, K, N);
+  hipblasStatus_t s2 = hipblasLtMatrixLayoutCreate(&p.a_desc, HIP_R_16F, K, M, K);
+  hipblasStatus_t s3 = hipblasLtMatrixLayoutCreate(&p.c_desc, HIP_R_16F, N, M, N);
+  if (s1 != HIPBLAS_STATUS_SUCCESS || s2 != HIPBLAS_STATUS_SUCCESS || s3 != HIPBLAS_STATUS_SUCCESS) {
+    p.destroy();
+    return HGEMM_ERR_BACKEND;
+  }
+  p.tn = tn; p.M = M; p.N = N; p.K = K; p.acc = acc;
+  p.compute16 = (compute == HIPBLAS_COMPUTE_16F);
+  return HGEMM_OK;
+}
+
+int lt_candidates(LtContext& ctx, LtProblem& p, int requested,
+                  std::vector<hipblasLtMatmulHeuristicResult_t>& out) {
+  hipblasLtMatmulPreference_t pref = nullptr;
+  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return HGEMM_ERR_BACKEND;
+  uint64_t ws = kLtWorkspaceBytes;
+  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
+  out.assign(requested, hipblasLtMatmulHeuristicResult_t());
+  int returned = 0;
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(ctx.handle, p.op, p.b_desc, p.a_desc, p.c_desc,
+                                                       p.c_desc, pref, requested, out.data(), &returned);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS) returned = 0;
+  out.resize(returned);
+  out.erase(std::remove_if(out.begin(), out.end(),
+                           [](const hipblasLtMatmulHeuristicResult_t& r) {
+                             return r.state != HIPBLAS_STATUS_SUCCESS || r.workspaceSize > kLtWorkspaceBytes;
+                           }),
+            out.end());
+  return out.empty() ? HGEMM_ERR_NO_ALGO : HGEMM_OK;
+}
+
+// Describe + enumerate; fp16-accumulate falls back to fp32 compute when hipBLASLt has no
+// COMPUTE_16F kernels for this problem (CDNA4 MFMA accumulates in fp32 regardless).
+int lt_prepare(LtContext& ctx, LtProblem& p, bool tn, int M, int N, int K, int acc, int requested,
+               std::vector<hipblasLtMatmulHeuristicResult_t>& cands) {
+  if (!ctx.handle) return HGEMM_ERR_NOT_READY;
+  int st = HGEMM_ERR_NO_ALGO;
+  if (acc == HGEMM_ACC_FP16) {
+    st = lt_describe(p, tn, M, N, K, acc, HIPBLAS_COMPUTE_16F);
+    if (st == HGEMM_OK) st = lt_candidates(ctx, p, requested, cands);
+  }
+  if (st != HGEMM_OK) {
+    st = lt_describe(p, tn, M, N, K, acc, HIPBLAS_COMPUTE_32F);
+    if (st == HGEMM_OK) st = lt_candidates(ctx, p, requested, cands);
+  }
+  if (st != HGEMM_OK) p.destroy();
+  return st;
+}
+
+int lt_matmul(LtContext& ctx, LtProblem& p, const hipblasLtMatmulAlgo_t* algo, const void* a,
+              const void* b, void* c, hipStream_t stream) {
+  const float alpha32 = 1.0f, beta32 = 0.0f;
+  const f16 alpha16 = (f16)1.0f, beta16 = (f16)0.0f;
+  const bool h = p.compute16;
+  hipblasStatus_t st = hipblasLtMatmul(ctx.handle, p.op, h ? (const void*)&alpha16 : (const void*)&alpha32, b,
+                                       p.b_desc, a, p.a_desc, h ? (const void*)&beta16 : (const void*)&beta32,
+                                       c, p.c_desc, c, p.c_desc, algo, ctx.workspace, kLtWorkspaceBytes, stream);
+  return st == HIPBLAS_STATUS_SUCCESS ? HGEMM_OK : HGEMM_ERR_BACKEND;
+}
+
+int heuristic_run(bool tn, const void* a, const void* b, void* c, int M, int N, int K, int acc,
+                  void* stream) {
+  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
+  if (!g_heur.handle) {
+    int st = lt_init(g_heur);
+    if (st != HGEMM_OK) return st;
+  }
+  LtProblem& p = tn ? g_heur.tn : g_heur.nn;
+  if (!p.matches(tn, M, N, K, acc) || !p.have_algo) {
+    std::vector<hipblasLtMatmulHeuristicResult_t> cands;
+    int st = lt_prepare(g_heur, p, tn, M, N, K, acc, 4, cands);  // top-1 of 4, as the reference
+    if (st != HGEMM_OK) return st;
+    p.algo = cands[0].algo;
+    p.have_algo = true;
+    p.candidates = (int)cands.size();
+  }
+  return lt_matmul(g_heur, p, &p.algo, a, b, c, (hipStream_t)stream);
+}
+
+double median_of(std::vector<float>& v) {
+  if (v.empty()) return 0.0;
+  std::sort(v.begin(), v.end());
+  const size_t mid = v.size() / 2;
+  return (v.size() % 2 == 0) ? 0.5 * (v[mid] + v[mid - 1]) : v[mid];
+}
+
+int autotune_find(bool tn, int M, int N, int K, int acc) {
+  if (M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
+  if (!g_auto.handle) return HGEMM_ERR_NOT_READY;
+  LtProblem& p = tn ? g_auto.tn : g_auto.nn;
+  std::vector<hipblasLtMatmulHeuristicResult_t> cands;
+  int st = lt_prepare(g_auto, p, tn, M, N, K, acc, 100, cands);
+  if (st != HGEMM_OK) return st;
+  const int n_algo = (int)cands.size();
+
+  f16 *a = nullptr, *b = nullptr, *c = nullptr;
+  if (hipMalloc(&a, (size_t)M * K * 2) != hipSuccess || hipMalloc(&b, (size_t)K * N * 2) != hipSuccess ||
+      hipMalloc(&c, (size_t)M * N * 2) != hipSuccess) {
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+    p.destroy();
+    return HGEMM_ERR_HIP;
+  }
+  hipStream_t stream;
+  hipStreamCreate(&stream);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+
+  int warm = 50, timed = 100;
+  {
+    // Time-box: estimate one GEMM at ~400 TFLOP/s and shrink the round counts if the
+    // reference's 150 rounds x n_algo would exceed the budget.
+    const char* env = getenv("HGEMM_AUTOTUNE_MAX_SECONDS");
+    const double budget = env ? atof(env) : 30.0;
+    const double est_ms = std::max(0.01, 2.0 * M * N * (double)K / 4.0e11);
+    const double full = (warm + timed) * (n_algo + 1) * est_ms * 1e-3;
+    if (budget > 0 && full > budget) {
+      const double f = budget / full;
+      warm = std::max(3, (int)(warm * f));
+      timed = std::max(5, (int)(timed * f));
+    }
+  }
+  std::vector<std::vector<float>> times(n_algo);
+  std::vector<bool> failed(n_algo, false);
+  std::mt19937 rng(std::random_device{}());
+  uint64_t seed = ((uint64_t)std::random_device{}() << 32) | std::random_device{}();
+  std::vector<int> order(n_algo);
+
+  for (int round = 0; round < warm + timed; ++round) {
+    hgemm_fill_normal_f16(a, (size_t)M * K, seed++, stream);
+    hgemm_fill_normal_f16(b, (size_t)K * N, seed++, stream);
+    hipStreamSynchronize(stream);
+    std::iota(order.begin(), order.end(), 0);
+    std::shuffle(order.begin(), order.end(), rng);
+    // untimed launch of the last candidate in this round's order (reference :211-225)
+    lt_matmul(g_auto, p, &cands[order[n_algo - 1]].algo, a, b, c, stream);
+    hipStreamSynchronize(stream);
+    for (int i = 0; i < n_algo; ++i) {
+      const int idx = order[i];
+      if (failed[idx]) continue;
+      hipEventRecord(e0, stream);
+      int rs = lt_matmul(g_auto, p, &cands[idx].algo, a, b, c, stream);
+      hipEventRecord(e1, stream);
+      hipEventSynchronize(e1);
+      if (rs != HGEMM_OK) { failed[idx] = true; continue; }
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (round >= warm) times[idx].push_back(ms);
+    }
+  }
+  int best = -1;
+  double best_ms = 1e30;
+  for (int i = 0; i < n_algo; ++i) {
+    if (failed[i] || times[i].empty()) continue;
+    const double med = median_of(times[i]);
+    if (med < best_ms) { best_ms = med; best = i; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(stream);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+  if (best < 0) { p.destroy(); return HGEMM_ERR_NO_ALGO; }
+  p.algo = cands[best].algo;
+  p.have_algo = true;
+  p.candidates = n_algo;
+  p.best_ms = best_ms;
+  return HGEMM_OK;
+}
+
+int autotune_run(bool tn, const void* a, const void* b, void* c, int M, int N, int K, int acc,
+                 void* stream) {
+  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
+  LtProblem& p = tn ? g_auto.tn : g_auto.nn;
+  // Like the reference (hgemm_cublaslt_auto_tuning.cu:466-546) the algorithm must have been
+  // selected by find_best_* for this very problem.
+  if (!g_auto.handle || !p.matches(tn, M, N, K, acc) || !p.have_algo) return HGEMM_ERR_NOT_READY;
+  return lt_matmul(g_auto, p, &p.algo, a, b, c, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hgemm_fill_normal_f16(void* device_ptr, size_t n, unsigned long long seed, void* stream) {
+  if (!device_ptr && n) return HGEMM_ERR_BAD_ARG;
+  if (n == 0) return HGEMM_OK;
+  size_t blocks = ((n + 1) / 2 + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(fill_normal_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (f16*)device_ptr, n, (uint64_t)seed);
+  return hipGetLastError() == hipSuccess ? HGEMM_OK : HGEMM_ERR_HIP;
+}
+
+int hgemm_rocblas_init(void) {
+  if (g_rocblas) return HGEMM_OK;
+  if (rocblas_create_handle(&g_rocblas) != rocblas_status_success) {
+    g_rocblas = nullptr;
+    return HGEMM_ERR_BACKEND;
+  }
+  return HGEMM_OK;
+}
+
+int hgemm_rocblas_destroy(void) {
+  if (g_rocblas) {
+    rocblas_destroy_handle(g_rocblas);
+    g_rocblas = nullptr;
+  }
+  return HGEMM_OK;
+}
+
+int hgemm_rocblas_nn(const void* a, const void* b, void* c, int M, int N, int K, int acc, void* stream) {
+  return rocblas_run(false, a, b, c, M, N, K, acc, stream);
+}
+int hgemm_rocblas_tn(const void* a, const void* bt, void* c, int M, int N, int K, int acc, void* stream) {
+  return rocblas_run(true, a, bt, c, M, N, K, acc, stream);
+}
+
+int hgemm_hipblaslt_heuristic_init(void) { return lt_init(g_heur); }
+int hgemm_hipblaslt_heuristic_destroy(void) { return lt_destroy(g_heur); }
+int hgemm_hipblaslt_heuristic_nn(const void* a, const void* b, void* c, int M, int N, int K, int acc, void* s) {
+  return heuristic_run(false, a, b, c, M, N, K, acc, s);
+}
+int hgemm_hipblaslt_heuristic_tn(const void* a, const void* bt, void* c, int M, int N, int K, int acc, void* s) {
+  return heuristic_run(true, a, bt, c, M, N, K, acc, s);
+}
+
+int hgemm_hipblaslt_autotune_init(void) { return lt_init(g_auto); }
+int hgemm_hipblaslt_autotune_destroy(void) { return lt_destroy(g_auto); }
+int hgemm_hipblaslt_autotune_find_best_nn(int M, int N, int K, int acc) { return autotune_find(false, M, N, K, acc); }
+int hgemm_hipblaslt_autotune_find_best_tn(int M, int N, int K, int acc) { return autotune_find(true, M, N, K, acc); }
+int hgemm_hipblaslt_autotune_nn(const void* a, const void* b, void* c, int M, int N, int K, int acc, void* s) {
+  return autotune_run(false, a, b, c, M, N, K, acc, s);
+}
+int hgemm_hipblaslt_autotune_tn(const void* a, const void* bt, void* c, int M, int N, int K, int acc, void* s) {
+  return autotune_run(true, a, bt, c, M, N, K, acc, s);
+}
+int hgemm_hipblaslt_autotune_candidates(int tn) { return (tn ? g_auto.tn : g_auto.nn).candidates; }
+double hgemm_hipblaslt_autotune_best_ms(int tn) { return (tn ? g_auto.tn : g_auto.nn).best_ms; }
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// Host-side launch thunks for the kernel instantiations listed in hgemm_configs.def.
+#pragma once
+#include "hgemm_kernel.hpp"
+
+namespace hgemm_mi355x {
+
+// One thunk per geometry; `splitk` selects the fp32-slab epilogue.  No per-call attribute
+// setting, allocation or synchronisation happens here (the reference calls
+// cudaFuncSetAttribute on every invocation, kernels/a100_F32F16F16F32/64_4096_64.cu:256-261).
+template <class CFG>
+void launch_cfg(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
+  if (splitk)
+    hipLaunchKernelGGL((hgemm_tn_kernel<CFG, true>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+  else
+    hipLaunchKernelGGL((hgemm_tn_kernel<CFG, false>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+}
+
+struct KernelEntry {
+  const char* name;
+  int bm, bn, wm, wn, mi, nbuf;
+  int threads, lds_bytes;
+  void (*launch)(const GemmArgs&, int, hipStream_t, bool);
+};
+
+extern const KernelEntry g_kernel_table[];
+extern const int g_num_kernels;
+
+void launch_splitk_reduce(const float* partial, f16* C, int M, int N, int ldc, int splits,
+                          hipStream_t stream);
+void launch_generic(const f16* A, const f16* B, f16* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, hipStream_t stream);
+
+}  // namespace hgemm_mi355x

@@ -1,0 +1,79 @@
+// Kernel registry (config id -> launch thunk) and the two helper kernels' launchers.
+#include "hgemm_launch.hpp"
+
+namespace hgemm_mi355x {
+
+#define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB) \
+  extern template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, bool);
+#include "hgemm_configs.def"
+#undef HGEMM_CFG
+
+// The table holds host function pointers: keep it out of the device pass.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define HGEMM_STR2(x) #x
+#define HGEMM_STR(x) HGEMM_STR2(x)
+#define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)                                                    \
+  {"t" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m" HGEMM_STR(MI)  \
+   "_s" HGEMM_STR(NB),                                                                         \
+   BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
+   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>},
+const KernelEntry g_kernel_table[] = {
+#include "hgemm_configs.def"
+};
+#undef HGEMM_CFG
+const int g_num_kernels = (int)(sizeof(g_kernel_table) / sizeof(g_kernel_table[0]));
+#endif  // !__HIP_DEVICE_COMPILE__
+
+// Split-K combine: C[m][n] = fp16( sum_s partial[s][m][n] ), fp32 adds in split order
+// (deterministic, unlike the reference's atomicAdd split-K, a100_F32F16F16F32/64_256_16384.cu:149-152).
+__global__ void __launch_bounds__(256) hgemm_splitk_reduce_kernel(const float* __restrict__ partial,
+                                                                  f16* __restrict__ C, int M, int N,
+                                                                  int ldc, int splits) {
+  const size_t total4 = ((size_t)M * N) >> 2;  // N % 4 == 0 on this path
+  const size_t slab   = (size_t)M * N;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4;
+       q += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = q << 2;
+    f32x4 s = *(const f32x4*)(partial + e);
+    for (int k = 1; k < splits; ++k) {
+      const f32x4 p = *(const f32x4*)(partial + (size_t)k * slab + e);
+      s += p;
+    }
+    const int m = (int)(e / N), n = (int)(e % N);
+    f16x4 o = {(f16)s[0], (f16)s[1], (f16)s[2], (f16)s[3]};
+    *(f16x4*)(C + (size_t)m * ldc + n) = o;
+  }
+}
+
+// Any-shape / any-alignment fallback (one output per thread, fp32 accumulate).  Correctness
+// net for shapes the MFMA path does not accept (K % 64 != 0, unaligned views); never tuned.
+__global__ void __launch_bounds__(256) hgemm_generic_kernel(const f16* __restrict__ A,
+                                                            const f16* __restrict__ B,
+                                                            f16* __restrict__ C, int M, int N, int K,
+                                                            int lda, int ldb_rowmajor, int ldc) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (m >= M || n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf((float)A[(size_t)m * lda + k], (float)B[(size_t)k * ldb_rowmajor + n], s);
+  C[(size_t)m * ldc + n] = (f16)s;
+}
+
+void launch_splitk_reduce(const float* partial, f16* C, int M, int N, int ldc, int splits,
+                          hipStream_t stream) {
+  const size_t quads = ((size_t)M * N) >> 2;
+  int grid = (int)((quads + 255) / 256);
+  if (grid > 256 * 8) grid = 256 * 8;  // grid-stride beyond 8 blocks per CU
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(hgemm_splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, partial, C, M, N,
+                     ldc, splits);
+}
+
+void launch_generic(const f16* A, const f16* B, f16* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, hipStream_t stream) {
+  dim3 grid((N + 63) / 64, (M + 3) / 4);
+  hipLaunchKernelGGL(hgemm_generic_kernel, grid, dim3(256), 0, stream, A, B, C, M, N, K, lda, ldb,
+                     ldc);
+}
+
+}  // namespace hgemm_mi355x

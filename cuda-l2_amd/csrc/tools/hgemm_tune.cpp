@@ -1,0 +1,376 @@
+// hgemm_tune -- native (no torch) checker / autotuner / micro-benchmark for libhgemm_mi355x.so.
+//
+//   hgemm_tune check [--shapes M_N_K,...]            every geometry x split-K vs the generic kernel
+//   hgemm_tune tune  --shapes M_N_K,... | --shape-file F  [--out F.jsonl] [--keep R] [--baselines]
+//                                                     time candidate plans, print one JSON line per shape
+//   hgemm_tune bench --shape M_N_K [--config NAME --splits S --group G] [--reps N] [--lib]
+//                                                     run one plan N times (for rocprofv3)
+//
+// This is the offline replacement for the reference's first-call in-process autotune variants
+// (h100 kernels that time several variants on first invocation): plans are
+// measured here, committed as csrc/hgemm_tuned_table.inc, and the hot path only does a table probe.
+// Timing: HIP events around each launch on the launch stream, operands N(0,1) (never zeros: DVFS,
+// MI355X_MICROARCH.md), buffer sets rotated so consecutive launches do not re-hit L2/MALL lines.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/hgemm_mi355x.h"
+
+#define HIP_OK(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                            \
+    }                                                                                     \
+  } while (0)
+
+typedef _Float16 f16;
+
+struct Shape { int M, N, K; };
+
+static std::vector<Shape> parse_shapes(const std::string& s) {
+  std::vector<Shape> out;
+  std::stringstream ss(s);
+  std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    Shape sh;
+    if (sscanf(tok.c_str(), "%d_%d_%d", &sh.M, &sh.N, &sh.K) == 3) out.push_back(sh);
+  }
+  return out;
+}
+
+static std::vector<Shape> read_shape_file(const char* path) {
+  std::vector<Shape> out;
+  std::ifstream f(path);
+  std::string line;
+  while (std::getline(f, line)) {
+    Shape sh;
+    if (sscanf(line.c_str(), "%d_%d_%d", &sh.M, &sh.N, &sh.K) == 3) out.push_back(sh);
+  }
+  return out;
+}
+
+struct Buffers {
+  f16 *a = nullptr, *b = nullptr, *bt = nullptr, *c = nullptr;
+};
+
+__global__ void transpose_kernel(const f16* __restrict__ b, f16* __restrict__ bt, int K, int N) {
+  // bt[n][k] = b[k][n]; small helper, not on any timed path
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)K * N) return;
+  const int n = (int)(idx / K), k = (int)(idx % K);
+  bt[idx] = b[(size_t)k * N + n];
+}
+
+static void alloc_set(Buffers& s, const Shape& sh, unsigned long long seed, bool need_b) {
+  HIP_OK(hipMalloc(&s.a, (size_t)sh.M * sh.K * 2));
+  HIP_OK(hipMalloc(&s.bt, (size_t)sh.N * sh.K * 2));
+  HIP_OK(hipMalloc(&s.c, (size_t)sh.M * sh.N * 2));
+  hgemm_fill_normal_f16(s.a, (size_t)sh.M * sh.K, seed * 3 + 1, nullptr);
+  if (need_b) {
+    HIP_OK(hipMalloc(&s.b, (size_t)sh.K * sh.N * 2));
+    hgemm_fill_normal_f16(s.b, (size_t)sh.K * sh.N, seed * 3 + 2, nullptr);
+    const size_t n = (size_t)sh.K * sh.N;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s.b, s.bt, sh.K, sh.N);
+  } else {
+    hgemm_fill_normal_f16(s.bt, (size_t)sh.N * sh.K, seed * 3 + 2, nullptr);
+  }
+  HIP_OK(hipDeviceSynchronize());
+}
+
+static void free_set(Buffers& s) {
+  if (s.a) HIP_OK(hipFree(s.a));
+  if (s.b) HIP_OK(hipFree(s.b));
+  if (s.bt) HIP_OK(hipFree(s.bt));
+  if (s.c) HIP_OK(hipFree(s.c));
+  s = Buffers();
+}
+
+static double median(std::vector<float> v) {
+  if (v.empty()) return 1e30;
+  std::sort(v.begin(), v.end());
+  const size_t m = v.size() / 2;
+  return v.size() % 2 ? v[m] : 0.5 * (v[m] + v[m - 1]);
+}
+
+struct Plan { int cfg, splits, group_m; double model_us; };
+
+// Time one callable over rotating buffer sets; returns median microseconds.
+template <class F>
+static double time_us(F&& launch, std::vector<Buffers>& sets, int warm, int reps, hipEvent_t e0, hipEvent_t e1) {
+  for (int i = 0; i < warm; ++i) launch(sets[i % sets.size()]);
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<float> t;
+  for (int i = 0; i < reps; ++i) {
+    Buffers& s = sets[i % sets.size()];
+    HIP_OK(hipEventRecord(e0, nullptr));
+    launch(s);
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    t.push_back(ms * 1000.f);
+  }
+  return median(t);
+}
+
+static int default_group(int cfg, const Shape& sh) {
+  // ask the library's own rule through plan-independent arithmetic: replicate default via plan()
+  // when the model picks the same config; otherwise use a square-ish guess.
+  int info[8];
+  hgemm_mi355x_config_info(cfg, info);
+  const int tm = (sh.M + info[0] - 1) / info[0], tn = (sh.N + info[1] - 1) / info[1];
+  const int per_xcd = std::max(1, (tm * tn + 7) / 8);
+  int g = 1;
+  while (g * g * 4 <= per_xcd * 2 && g * 2 <= tm) g *= 2;
+  return std::max(1, std::min(g, tm));
+}
+
+static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_cand) {
+  std::vector<Plan> all;
+  const int nc = hgemm_mi355x_num_configs();
+  const int ksteps = sh.K / 64;
+  for (int c = 0; c < nc; ++c) {
+    int info[8];
+    hgemm_mi355x_config_info(c, info);
+    if (info[0] > sh.M * 2 && info[0] > 32) continue;
+    if (info[1] > sh.N * 2 && info[1] > 32) continue;
+    for (int s = 1; s <= 64; s *= 2) {
+      if (s > 1 && ksteps / s < 2) break;
+      const long wgs = (long)((sh.M + info[0] - 1) / info[0]) * ((sh.N + info[1] - 1) / info[1]) * s;
+      if (s > 1 && wgs > 256L * 12) break;  // split-K only to fill the chip
+      all.push_back({c, s, default_group(c, sh), hgemm_mi355x_model_us(c, s, sh.M, sh.N, sh.K)});
+    }
+  }
+  std::sort(all.begin(), all.end(), [](const Plan& a, const Plan& b) { return a.model_us < b.model_us; });
+  std::vector<Plan> out;
+  for (const Plan& p : all) {
+    if ((int)out.size() >= max_cand) break;
+    if (!out.empty() && p.model_us > all[0].model_us * keep_ratio && (int)out.size() >= 4) break;
+    out.push_back(p);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int cmd_check(const std::vector<Shape>& shapes) {
+  int failures = 0, runs = 0;
+  const int nc = hgemm_mi355x_num_configs();
+  for (const Shape& sh : shapes) {
+    Buffers s;
+    alloc_set(s, sh, 1234 + sh.M + sh.N * 3 + sh.K * 7, true);
+    const size_t cn = (size_t)sh.M * sh.N;
+    f16* ref_d;
+    HIP_OK(hipMalloc(&ref_d, cn * 2));
+    int st = hgemm_mi355x_launch(-1, 1, 1, s.a, s.b, s.bt, ref_d, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+    if (st != HGEMM_OK) { fprintf(stderr, "generic launch failed: %s\n", hgemm_mi355x_strerror(st)); return 2; }
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<f16> ref(cn), got(cn);
+    HIP_OK(hipMemcpy(ref.data(), ref_d, cn * 2, hipMemcpyDeviceToHost));
+    double ref_max = 0;
+    for (size_t i = 0; i < cn; ++i) ref_max = std::max(ref_max, (double)fabsf((float)ref[i]));
+    for (int c = 0; c < nc; ++c) {
+      for (int splits : {1, 2, 3, 8}) {
+        if (splits > 1 && sh.K / 64 < splits) continue;
+        for (int group : {1, 4}) {
+          if (group > 1 && splits > 1) continue;
+          HIP_OK(hipMemset(s.c, 0xff, cn * 2));  // NaN pattern: unwritten outputs are caught
+          st = hgemm_mi355x_launch(c, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+          hipError_t e = hipDeviceSynchronize();
+          ++runs;
+          if (st != HGEMM_OK || e != hipSuccess) {
+            printf("FAIL %d_%d_%d %s s=%d g=%d: status %d hip %d\n", sh.M, sh.N, sh.K, hgemm_mi355x_config_name(c), splits, group, st, (int)e);
+            ++failures;
+            if (e != hipSuccess) return 3;
+            continue;
+          }
+          HIP_OK(hipMemcpy(got.data(), s.c, cn * 2, hipMemcpyDeviceToHost));
+          double max_err = 0;
+          size_t bad = 0;
+          for (size_t i = 0; i < cn; ++i) {
+            const float g = (float)got[i], r = (float)ref[i];
+            const double err = (g == g) ? fabs((double)g - r) : 1e30;
+            // both sides accumulate in fp32 (different order) and round once to fp16
+            if (err > 2e-3 * ref_max + 1e-3) ++bad;
+            if (err > max_err) max_err = err;
+          }
+          if (bad) {
+            printf("FAIL %d_%d_%d %s s=%d g=%d: %zu/%zu elements off, max_err %.4g (ref_max %.4g)\n", sh.M, sh.N, sh.K,
+                   hgemm_mi355x_config_name(c), splits, group, bad, cn, max_err, ref_max);
+            ++failures;
+          }
+        }
+      }
+    }
+    HIP_OK(hipFree(ref_d));
+    free_set(s);
+    printf("checked %d_%d_%d\n", sh.M, sh.N, sh.K);
+    fflush(stdout);
+  }
+  printf("check: %d runs, %d failures\n", runs, failures);
+  return failures ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, double keep_ratio, int max_cand,
+                    bool baselines, bool sweep_group) {
+  FILE* out = out_path ? fopen(out_path, "a") : stdout;
+  if (!out) { perror("open --out"); return 2; }
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  if (baselines) {
+    hgemm_rocblas_init();
+    hgemm_hipblaslt_heuristic_init();
+  }
+  for (const Shape& sh : shapes) {
+    const double flops = 2.0 * sh.M * sh.N * (double)sh.K;
+    const size_t set_bytes = 2 * ((size_t)sh.M * sh.K + (size_t)sh.N * sh.K * (baselines ? 2 : 1) + (size_t)sh.M * sh.N);
+    // rotate enough buffer sets to exceed L2 + MALL (~288 MiB), capped at 6 GiB total
+    int nsets = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)320 << 20) / set_bytes + 1));
+    while (nsets > 1 && (size_t)nsets * set_bytes > ((size_t)6 << 30)) --nsets;
+    std::vector<Buffers> sets(nsets);
+    for (int i = 0; i < nsets; ++i) alloc_set(sets[i], sh, 77 + i, baselines);
+
+    std::vector<Plan> cands = candidates(sh, keep_ratio, max_cand);
+    struct Res { Plan p; double us; };
+    std::vector<Res> res;
+    for (const Plan& p : cands) {
+      const double est_us = std::max(2.0, p.model_us);
+      int reps = (int)std::max(3.0, std::min(30.0, 20000.0 / est_us));
+      if (flops > 1.5e12) reps = 2;
+      auto launch = [&](Buffers& s) {
+        hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+      };
+      const double us = time_us(launch, sets, flops > 1.5e12 ? 1 : 2, reps, e0, e1);
+      res.push_back({p, us});
+    }
+    std::sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.us < b.us; });
+    if (sweep_group && !res.empty() && flops <= 1.5e12) {
+      Res best = res[0];
+      for (int g : {1, 2, 4, 8, 16, 32}) {
+        if (g == best.p.group_m) continue;
+        Plan p = best.p;
+        p.group_m = g;
+        auto launch = [&](Buffers& s) {
+          hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+        };
+        const double us = time_us(launch, sets, 1, std::max(3, (int)std::min(20.0, 20000.0 / best.us)), e0, e1);
+        res.push_back({p, us});
+      }
+      std::sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.us < b.us; });
+    }
+    double rb_nn = -1, rb_tn = -1, lt_nn = -1, lt_tn = -1;
+    if (baselines) {
+      const int reps = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
+      rb_nn = time_us([&](Buffers& s) { hgemm_rocblas_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      rb_tn = time_us([&](Buffers& s) { hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      lt_nn = time_us([&](Buffers& s) { hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      lt_tn = time_us([&](Buffers& s) { hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+    }
+    fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
+            sh.M, sh.N, sh.K, hgemm_mi355x_config_name(res[0].p.cfg), res[0].p.splits, res[0].p.group_m, res[0].us,
+            flops / res[0].us * 1e-6);
+    if (baselines)
+      fprintf(out, ", \"rocblas_nn_us\": %.3f, \"rocblas_tn_us\": %.3f, \"hipblaslt_heur_nn_us\": %.3f, \"hipblaslt_heur_tn_us\": %.3f",
+              rb_nn, rb_tn, lt_nn, lt_tn);
+    fprintf(out, ", \"candidates\": [");
+    for (size_t i = 0; i < res.size(); ++i)
+      fprintf(out, "%s{\"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"model_us\": %.2f}", i ? ", " : "",
+              hgemm_mi355x_config_name(res[i].p.cfg), res[i].p.splits, res[i].p.group_m, res[i].us, res[i].p.model_us);
+    fprintf(out, "]}\n");
+    fflush(out);
+    for (auto& s : sets) free_set(s);
+  }
+  if (out != stdout) fclose(out);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int group, int reps, bool use_lib_plan) {
+  int cfg = -2;
+  if (use_lib_plan || !cfg_name) {
+    hgemm_mi355x_plan(sh.M, sh.N, sh.K, &cfg, &splits, &group);
+  } else {
+    cfg = hgemm_mi355x_config_by_name(cfg_name);
+    if (cfg < 0) { fprintf(stderr, "unknown config %s\n", cfg_name); return 2; }
+    if (group <= 0) group = default_group(cfg, sh);
+  }
+  const size_t set_bytes = 2 * ((size_t)sh.M * sh.K + (size_t)sh.N * sh.K + (size_t)sh.M * sh.N);
+  int nsets = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)320 << 20) / set_bytes + 1));
+  std::vector<Buffers> sets(nsets);
+  for (int i = 0; i < nsets; ++i) alloc_set(sets[i], sh, 5 + i, false);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  auto launch = [&](Buffers& s) {
+    hgemm_mi355x_launch(cfg, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+  };
+  const double us = time_us(launch, sets, 3, reps, e0, e1);
+  const double flops = 2.0 * sh.M * sh.N * (double)sh.K;
+  printf("{\"mnk\": \"%d_%d_%d\", \"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f, \"reps\": %d}\n",
+         sh.M, sh.N, sh.K, cfg >= 0 ? hgemm_mi355x_config_name(cfg) : "generic", splits, group, us, flops / us * 1e-6, reps);
+  for (auto& s : sets) free_set(s);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: hgemm_tune check|tune|bench [options]\n");
+    return 2;
+  }
+  std::string mode = argv[1];
+  std::vector<Shape> shapes;
+  const char* out_path = nullptr;
+  const char* cfg_name = nullptr;
+  double keep = 2.5;
+  int max_cand = 12, splits = 1, group = 0, reps = 20;
+  bool baselines = false, use_lib = false, sweep_group = false;
+  for (int i = 2; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
+    if (a == "--shapes" || a == "--shape") { auto v = parse_shapes(next()); shapes.insert(shapes.end(), v.begin(), v.end()); }
+    else if (a == "--shape-file") { auto v = read_shape_file(next()); shapes.insert(shapes.end(), v.begin(), v.end()); }
+    else if (a == "--out") out_path = next();
+    else if (a == "--keep") keep = atof(next());
+    else if (a == "--max-cand") max_cand = atoi(next());
+    else if (a == "--baselines") baselines = true;
+    else if (a == "--sweep-group") sweep_group = true;
+    else if (a == "--config") cfg_name = next();
+    else if (a == "--splits") splits = atoi(next());
+    else if (a == "--group") group = atoi(next());
+    else if (a == "--reps") reps = atoi(next());
+    else if (a == "--lib") use_lib = true;
+    else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    fprintf(stderr, "hgemm_tune: no HIP device visible\n");
+    return 3;
+  }
+  if (mode == "check") {
+    if (shapes.empty())
+      shapes = parse_shapes("64_64_64,64_4096_64,128_192_256,200_136_128,256_256_1024,320_448_512,512_1024_2048,1000_520_192");
+    return cmd_check(shapes);
+  }
+  if (mode == "tune") {
+    if (shapes.empty()) { fprintf(stderr, "tune needs --shapes / --shape-file\n"); return 2; }
+    return cmd_tune(shapes, out_path, keep, max_cand, baselines, sweep_group);
+  }
+  if (mode == "bench") {
+    if (shapes.empty()) { fprintf(stderr, "bench needs --shape\n"); return 2; }
+    return cmd_bench(shapes[0], cfg_name, splits, group, reps, use_lib);
+  }
+  fprintf(stderr, "unknown mode %s\n", mode.c_str());
+  return 2;
+}
