@@ -16,6 +16,7 @@ using namespace hgemm_mi355x;
 namespace {
 
 int g_last_hip_error = 0;
+int g_debug_flags = 0;  // HGEMM_MI355X_DEBUG (ablation experiments of the tuner; never set in production)
 
 // ---- split-K workspace ------------------------------------------------------------------------
 std::mutex g_ws_mutex;
@@ -242,6 +243,7 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, c
     g.k_chunk = steps_per_split * BK;
     g.splits = splits;
     g.group_m = std::max(1, std::min(group_m, g.tiles_m));
+    g.debug = g_debug_flags;
     const long grid = (long)g.tiles_m * g.tiles_n * splits;
     if (grid > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
     if (splits > 1) {
@@ -280,6 +282,8 @@ const char* hgemm_mi355x_strerror(int status) {
 }
 
 int hgemm_mi355x_last_hip_error(void) { return g_last_hip_error; }
+
+int hgemm_mi355x_set_debug(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 
 const char* hgemm_mi355x_version(void) { return "hgemm_mi355x 0.1 (gfx950)"; }
 

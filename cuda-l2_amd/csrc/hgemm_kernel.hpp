@@ -57,6 +57,7 @@ struct GemmArgs {
   int splits;
   int tiles_m, tiles_n;
   int group_m;     // rasterisation group height in tiles
+  int debug;       // bit 0: skip steady-state LDS-DMA (ablation only; results are garbage)
 };
 
 // Compile-time geometry of one kernel instantiation.
@@ -86,6 +87,79 @@ struct Cfg {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Block id -> (split, tile origin, K range): XCD-bijective remap + grouped rasterisation.
+// The dispatcher places block b on XCD b % 8 (observed, used for speed only); the remap hands
+// each XCD one contiguous run of logical tile ids, and the grouped raster makes that run a
+// compact patch of the tile grid, so the A/B panels a patch shares are hit in that XCD's L2.
+struct TileCoord { int split, m0, n0, k_begin, nk; };
+
+__device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN) {
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
+    const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int split = bid / tiles;
+  const int t_id  = bid - split * tiles;
+  const int gsz   = g.group_m * g.tiles_n;
+  const int grp   = t_id / gsz;
+  const int first_m = grp * g.group_m;
+  const int gm    = min(g.tiles_m - first_m, g.group_m);
+  const int tin   = t_id - grp * gsz;
+  TileCoord tc;
+  tc.split = split;
+  tc.m0 = (first_m + tin % gm) * BM;
+  tc.n0 = (tin / gm) * BN;
+  tc.k_begin = split * g.k_chunk;
+  tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin) / BK;
+  return tc;
+}
+
+// Epilogue shared by the kernel families (MI = 16 or 32 accumulator layout, operands swapped):
+// lane holds C[m][n .. n+3] (4 consecutive N) per accumulator quad.
+//   MI=16: m = (lane & 15),  n = (lane >> 4) * 4 + e                       (e = 0..3)
+//   MI=32: m = (lane & 31),  n = 8 * q + 4 * (lane >> 5) + e,  reg = 4*q+e (q = 0..3)
+// The host only takes the MFMA path when N % 4 == 0, ldc % 4 == 0 and C is 8-byte aligned, so a
+// quad is either fully inside or fully outside the matrix.
+template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, class ACC>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& tc, int wave_m,
+                                           int wave_n, int lane, ACC (&acc)[FM][FN]) {
+  const int lm = (MI == 16) ? (lane & 15) : (lane & 31);
+  const int ln = (MI == 16) ? ((lane >> 4) * 4) : ((lane >> 5) * 4);
+  constexpr int NQ = (MI == 16) ? 1 : 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    // keep the accumulator -> VGPR traffic of one fragment row together: without the fence the
+    // scheduler hoists all FM*FN*4 accumulator reads ahead of the first store, and at 256
+    // accumulators per lane that pressure leaks into the main loop's register allocation
+    __builtin_amdgcn_sched_barrier(0);
+    const int m = tc.m0 + wave_m * TM + i * MI + lm;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int n = tc.n0 + wave_n * TN + j * MI + q * 8 + ln;
+        if (m < g.M && n < g.N) {
+          if constexpr (SPLITK) {
+            float* dst = g.partial + ((size_t)tc.split * g.M + m) * g.N + n;
+            f32x4 o = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
+                       acc[i][j][q * 4 + 3]};
+            *(f32x4*)dst = o;
+          } else {
+            f16* dst = g.C + (size_t)m * g.ldc + n;
+            f16x4 o = {(f16)acc[i][j][q * 4 + 0], (f16)acc[i][j][q * 4 + 1],
+                       (f16)acc[i][j][q * 4 + 2], (f16)acc[i][j][q * 4 + 3]};
+            *(f16x4*)dst = o;
+          }
+        }
+      }
+    }
+  }
 }
 
 // The buffer-resource builtins only exist in the device pass; the host pass just needs the
@@ -125,30 +199,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
   const int wave_m = wave / CFG::WN;
   const int wave_n = wave % CFG::WN;
 
-  // ---- block id -> (split, tile_m, tile_n): XCD-bijective remap + grouped raster ----------
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
-    const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tiles = g.tiles_m * g.tiles_n;
-  const int split = bid / tiles;
-  const int t_id  = bid - split * tiles;
-  const int gsz   = g.group_m * g.tiles_n;
-  const int grp   = t_id / gsz;
-  const int first_m = grp * g.group_m;
-  const int gm    = min(g.tiles_m - first_m, g.group_m);
-  const int tin   = t_id - grp * gsz;
-  const int tile_m = first_m + tin % gm;
-  const int tile_n = tin / gm;
-  const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
-
-  const int k_begin = split * g.k_chunk;
-  const int k_end   = min(g.K, k_begin + g.k_chunk);
-  const int nk      = (k_end - k_begin) / BK;
+  const TileCoord tc = map_block(g, BM, BN);
+  const int split = tc.split, m0 = tc.m0, n0 = tc.n0, k_begin = tc.k_begin, nk = tc.nk;
 
   // ---- LDS-DMA source addressing ------------------------------------------------------------
   // One descriptor per operand, based at the tile's first row; rows past the matrix edge are
@@ -220,7 +272,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // all waves' pieces of tile t landed; stage `wr` is free again
 
-    if (t + NBUF - 1 < nk) {
+    if (t + NBUF - 1 < nk && !(g.debug & 1)) {
       stage_tile<CFG>(rsA, rsB, voff, smem + wr * CFG::STAGE_BYTES, wave, kbyte);
       kbyte += ROW_BYTES;
     }
@@ -250,38 +302,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
-  // Swapped-operand MFMA: lane holds C[m][n .. n+3] (4 consecutive N) per accumulator quad.
-  //   MI=16: m = (lane & 15),  n = (lane >> 4) * 4 + e                       (e = 0..3)
-  //   MI=32: m = (lane & 31),  n = 8 * q + 4 * (lane >> 5) + e,  reg = 4*q+e (q = 0..3)
-  // The host only takes this path when N % 4 == 0, ldc % 4 == 0 and C is 8-byte aligned, so a
-  // quad is either fully inside or fully outside the matrix.
-  const int lm = (MI == 16) ? (lane & 15) : (lane & 31);
-  const int ln = (MI == 16) ? ((lane >> 4) * 4) : ((lane >> 5) * 4);
-  constexpr int NQ = (MI == 16) ? 1 : 4;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wave_m * CFG::TM + i * MI + lm;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int n = n0 + wave_n * CFG::TN + j * MI + q * 8 + ln;
-        if (m < g.M && n < g.N) {
-          if constexpr (SPLITK) {
-            float* dst = g.partial + ((size_t)split * g.M + m) * g.N + n;
-            f32x4 o = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
-                       acc[i][j][q * 4 + 3]};
-            *(f32x4*)dst = o;
-          } else {
-            f16* dst = g.C + (size_t)m * g.ldc + n;
-            f16x4 o = {(f16)acc[i][j][q * 4 + 0], (f16)acc[i][j][q * 4 + 1],
-                       (f16)acc[i][j][q * 4 + 2], (f16)acc[i][j][q * 4 + 3]};
-            *(f16x4*)dst = o;
-          }
-        }
-      }
-    }
-  }
+  (void)split;
+  store_tile<MI, FM, FN, CFG::TM, CFG::TN, SPLITK>(g, tc, wave_m, wave_n, lane, acc);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -1,6 +1,7 @@
 // Host-side launch thunks for the kernel instantiations listed in hgemm_configs.def.
 #pragma once
-#include "hgemm_kernel.hpp"
+#include "hgemm_kernel_pp.hpp"
+#include "hgemm_kernel_sp.hpp"
 
 namespace hgemm_mi355x {
 
@@ -13,6 +14,29 @@ void launch_cfg(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
     hipLaunchKernelGGL((hgemm_tn_kernel<CFG, true>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
   else
     hipLaunchKernelGGL((hgemm_tn_kernel<CFG, false>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+}
+
+template <class CFG>
+void launch_pp(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
+  if constexpr (CFG::MODE == 0) {
+    if (splitk)
+      hipLaunchKernelGGL((hgemm_tn_pp_kernel<CFG, true>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+    else
+      hipLaunchKernelGGL((hgemm_tn_pp_kernel<CFG, false>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+  } else {
+    if (splitk)
+      hipLaunchKernelGGL((hgemm_tn_cp_kernel<CFG, true>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+    else
+      hipLaunchKernelGGL((hgemm_tn_cp_kernel<CFG, false>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+  }
+}
+
+template <class CFG>
+void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
+  if (splitk)
+    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, true>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+  else
+    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, false>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
 }
 
 struct KernelEntry {

@@ -5,8 +5,14 @@ namespace hgemm_mi355x {
 
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB) \
   extern template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, bool);
+#define HGEMM_PP(G, BM, BN, WM, WN, MODE) \
+  extern template void launch_pp<CfgPP<BM, BN, WM, WN, MODE>>(const GemmArgs&, int, hipStream_t, bool);
+#define HGEMM_SP(G, BM, BN, WM, WN) \
+  extern template void launch_sp<CfgSP<BM, BN, WM, WN>>(const GemmArgs&, int, hipStream_t, bool);
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
+#undef HGEMM_PP
+#undef HGEMM_SP
 
 // The table holds host function pointers: keep it out of the device pass.
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -17,10 +23,33 @@ namespace hgemm_mi355x {
    "_s" HGEMM_STR(NB),                                                                         \
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
    Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>},
+#define HGEMM_PP(G, BM, BN, WM, WN, MODE)
+#define HGEMM_SP(G, BM, BN, WM, WN)
 const KernelEntry g_kernel_table[] = {
+#include "hgemm_configs.def"
+#undef HGEMM_CFG
+#undef HGEMM_PP
+#undef HGEMM_SP
+#define HGEMM_SP(G, BM, BN, WM, WN)
+#define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
+#define HGEMM_PP(G, BM, BN, WM, WN, MODE)                                                        \
+  {"p" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_v" HGEMM_STR(MODE), BM, \
+   BN, WM, WN, 16, 4, CfgPP<BM, BN, WM, WN, MODE>::THREADS, CfgPP<BM, BN, WM, WN, MODE>::LDS_BYTES,  \
+   &launch_pp<CfgPP<BM, BN, WM, WN, MODE>>},
+#include "hgemm_configs.def"
+#undef HGEMM_CFG
+#undef HGEMM_PP
+#undef HGEMM_SP
+#define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
+#define HGEMM_PP(G, BM, BN, WM, WN, MODE)
+#define HGEMM_SP(G, BM, BN, WM, WN)                                                             \
+  {"s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN), BM, BN, WM, WN, 16, 2, \
+   CfgSP<BM, BN, WM, WN>::THREADS, CfgSP<BM, BN, WM, WN>::LDS_BYTES, &launch_sp<CfgSP<BM, BN, WM, WN>>},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG
+#undef HGEMM_PP
+#undef HGEMM_SP
 const int g_num_kernels = (int)(sizeof(g_kernel_table) / sizeof(g_kernel_table[0]));
 #endif  // !__HIP_DEVICE_COMPILE__
 

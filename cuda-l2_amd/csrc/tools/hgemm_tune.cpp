@@ -60,6 +60,9 @@ static std::vector<Shape> read_shape_file(const char* path) {
   return out;
 }
 
+static int g_ld_override = -1;     // --ld N: pass lda = ldb = N (0 = every tile row aliases row 0: cache-hit ablation)
+static bool g_zero_fill = false;  // --fill zero: DVFS experiment only (never for quoted numbers)
+
 struct Buffers {
   f16 *a = nullptr, *b = nullptr, *bt = nullptr, *c = nullptr;
 };
@@ -72,10 +75,19 @@ __global__ void transpose_kernel(const f16* __restrict__ b, f16* __restrict__ bt
   bt[idx] = b[(size_t)k * N + n];
 }
 
-static void alloc_set(Buffers& s, const Shape& sh, unsigned long long seed, bool need_b) {
+static void alloc_set(Buffers& s, const Shape& shape, unsigned long long seed, bool need_b) {
+  Shape sh = shape;
+  if (g_ld_override > sh.K) sh.K = g_ld_override;  // padded-row experiment: rows are ld apart
   HIP_OK(hipMalloc(&s.a, (size_t)sh.M * sh.K * 2));
   HIP_OK(hipMalloc(&s.bt, (size_t)sh.N * sh.K * 2));
   HIP_OK(hipMalloc(&s.c, (size_t)sh.M * sh.N * 2));
+  if (g_zero_fill) {
+    HIP_OK(hipMemset(s.a, 0, (size_t)sh.M * sh.K * 2));
+    HIP_OK(hipMemset(s.bt, 0, (size_t)sh.N * sh.K * 2));
+    if (need_b) { HIP_OK(hipMalloc(&s.b, (size_t)sh.K * sh.N * 2)); HIP_OK(hipMemset(s.b, 0, (size_t)sh.K * sh.N * 2)); }
+    HIP_OK(hipDeviceSynchronize());
+    return;
+  }
   hgemm_fill_normal_f16(s.a, (size_t)sh.M * sh.K, seed * 3 + 1, nullptr);
   if (need_b) {
     HIP_OK(hipMalloc(&s.b, (size_t)sh.K * sh.N * 2));
@@ -313,8 +325,9 @@ static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int grou
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
+  const int ld = g_ld_override >= 0 ? g_ld_override : sh.K;
   auto launch = [&](Buffers& s) {
-    hgemm_mi355x_launch(cfg, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+    hgemm_mi355x_launch(cfg, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, ld, ld, sh.N, nullptr);
   };
   const double us = time_us(launch, sets, 3, reps, e0, e1);
   const double flops = 2.0 * sh.M * sh.N * (double)sh.K;
@@ -351,6 +364,9 @@ int main(int argc, char** argv) {
     else if (a == "--group") group = atoi(next());
     else if (a == "--reps") reps = atoi(next());
     else if (a == "--lib") use_lib = true;
+    else if (a == "--ld") g_ld_override = atoi(next());
+    else if (a == "--debug") hgemm_mi355x_set_debug(atoi(next()));
+    else if (a == "--fill") g_zero_fill = (std::string(next()) == "zero");
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
   int ndev = 0;

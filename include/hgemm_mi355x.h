@@ -92,6 +92,9 @@ size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits);
 const char* hgemm_mi355x_strerror(int status);
 int hgemm_mi355x_last_hip_error(void);
 const char* hgemm_mi355x_version(void);
+/* Ablation switches for the native tuner (bit 0: skip steady-state LDS-DMA -> wrong results,
+ * timing only).  Returns the previous value.  Never set by the library itself. */
+int hgemm_mi355x_set_debug(int flags);
 
 /* ------------------------------------------------------------------------------------------
  * Vendor baselines (same tensors, same process, as in the reference's cublas/ tree).

@@ -1,0 +1,108 @@
+"""CPU checks of the HIP kernel's addressing (see tests/kernel_layout_model.py)."""
+import re
+
+import numpy as np
+import pytest
+
+import kernel_layout_model as klm
+
+
+def _configs_from_def(pkg_dir):
+    text = (pkg_dir / "csrc" / "hgemm_configs.def").read_text()
+    out = []
+    for m in re.finditer(r"^HGEMM_CFG\(\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", text, re.M):
+        _, bm, bn, wm, wn, mi, nbuf = map(int, m.groups())
+        out.append((bm, bn, wm, wn, mi, nbuf))
+    return out
+
+
+def test_config_table_is_consistent(pkg_dir):
+    cfgs = _configs_from_def(pkg_dir)
+    assert len(cfgs) >= 20
+    assert len(set(cfgs)) == len(cfgs), "duplicate geometry"
+    for bm, bn, wm, wn, mi, nbuf in cfgs:
+        g = klm.Geometry(bm, bn, wm, wn, mi, nbuf)
+        assert bm % (wm * mi) == 0 and bn % (wn * mi) == 0
+        assert g.STAGE_BYTES * nbuf <= 160 * 1024
+        if nbuf > 2:  # counted vmcnt assumes an even DMA piece split
+            assert g.NI % g.NW == 0
+
+
+@pytest.mark.parametrize("geo", [(64, 64, 2, 2, 16), (32, 32, 1, 1, 16), (64, 32, 2, 1, 16), (64, 64, 1, 1, 32), (128, 64, 2, 2, 32)])
+def test_tile_matches_numpy_and_is_bank_conflict_free(geo):
+    rng = np.random.default_rng(0)
+    g = klm.Geometry(*geo)
+    M, N, K = g.BM + 8, g.BN + 12, 128          # ragged edges: second tile row/col is partial
+    A = rng.integers(-3, 4, size=(M, K)).astype(np.float32)
+    Bt = rng.integers(-3, 4, size=(N, K)).astype(np.float32)   # asymmetric operands
+    ref = A @ Bt.T
+    for (m0, n0) in [(0, 0), (g.BM, 0), (0, g.BN), (g.BM, g.BN)]:
+        out, conflicts = klm.run_tile(g, A, Bt, m0, n0)
+        assert conflicts == 0, "swizzle must make every ds_read_b128 conflict-free"
+        rows = range(m0, min(M, m0 + g.BM))
+        cols = range(n0, min(N, n0 + g.BN))
+        assert len(out) == len(rows) * len(cols), "every in-range C element written exactly once"
+        for m in rows:
+            for n in cols:
+                assert out[(m, n)] == ref[m, n], (m, n)
+
+
+def test_linear_lds_would_conflict():
+    """Sanity of the conflict model itself: without the XOR the same reads are 4-way conflicted."""
+    g = klm.Geometry(64, 64, 2, 2, 16)
+    addrs = [(lane & 15) * 128 + ((lane >> 4) << 4) for lane in range(64)]
+    assert klm.bank_conflict_extra_cycles(addrs) > 0
+    addrs_sw = [klm.frag_offsets(g, lane)[0] for lane in range(64)]
+    assert klm.bank_conflict_extra_cycles(addrs_sw) == 0
+
+
+@pytest.mark.parametrize("nwg", [1, 7, 8, 9, 31, 32, 100, 256, 257, 1000])
+def test_xcd_remap_is_a_bijection(nwg):
+    seen = sorted(klm.remap_block(b, nwg) for b in range(nwg))
+    assert seen == list(range(nwg))
+
+
+@pytest.mark.parametrize("tm,tn,gm,splits", [(1, 1, 1, 1), (16, 16, 4, 1), (5, 7, 4, 1), (3, 64, 8, 2), (9, 2, 16, 3)])
+def test_raster_covers_every_tile_once(tm, tn, gm, splits):
+    gm = min(gm, tm)
+    seen = set()
+    for bid in range(tm * tn * splits):
+        s, m, n = klm.tile_of(bid, tm, tn, gm)
+        assert 0 <= m < tm and 0 <= n < tn and 0 <= s < splits
+        seen.add((s, m, n))
+    assert len(seen) == tm * tn * splits
+
+
+def test_xcd_chunks_are_compact():
+    """Blocks that land on one XCD (bid % 8) should cover a compact patch of the tile grid."""
+    tm = tn = 16
+    nwg = tm * tn
+    for xcd in range(8):
+        tiles = [klm.tile_of(klm.remap_block(b, nwg), tm, tn, 4)[1:] for b in range(xcd, nwg, 8)]
+        rows = {t[0] for t in tiles}
+        cols = {t[1] for t in tiles}
+        # 32 tiles per XCD as a 4 x 8 patch -> 12 operand panels instead of up to 32
+        assert len(rows) + len(cols) <= 12
+
+
+@pytest.mark.parametrize("geo", [(128, 128, 2, 4), (128, 256, 2, 4), (256, 128, 4, 2)])
+def test_pingpong_tile_matches_numpy_and_is_bank_conflict_free(geo):
+    rng = np.random.default_rng(1)
+    g = klm.GeometryPP(*geo)
+    M, N, K = g.BM + 24, g.BN + 4, 64
+    A = rng.integers(-3, 4, size=(M, K)).astype(np.float32)
+    Bt = rng.integers(-3, 4, size=(N, K)).astype(np.float32)
+    ref = A @ Bt.T
+    for (m0, n0) in [(0, 0), (g.BM, g.BN)]:
+        out, conflicts = klm.run_tile_pp(g, A, Bt, m0, n0)
+        assert conflicts == 0
+        rows, cols = range(m0, min(M, m0 + g.BM)), range(n0, min(N, n0 + g.BN))
+        assert len(out) == len(rows) * len(cols)
+        for m in rows:
+            for n in cols:
+                assert out[(m, n)] == ref[m, n], (m, n)
+
+
+@pytest.mark.parametrize("NU", [2, 3, 4, 5, 6, 8, 9, 32, 128])
+def test_pingpong_schedule_has_no_lds_hazard(NU):
+    assert klm.pp_schedule_hazards(NU) == []
