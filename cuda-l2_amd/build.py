@@ -128,6 +128,43 @@ def build_tools(verbose: bool = False) -> list[Path]:
     return out
 
 
+def _torch_build_env():
+    import sysconfig
+
+    from torch.utils.cpp_extension import include_paths, library_paths
+
+    incs = include_paths() + [sysconfig.get_paths()["include"], str(ROCM / "include")]
+    return incs, library_paths()
+
+
+def build_extension(kernel_src: Path, pybind_src: Path, base_dir: Path, name: str = "hgemm_lib",
+                    verbose: bool = False) -> Path:
+    """Link {base_dir}/{name}.so = torch shim (pybind_src) + per-shape plan (kernel_src) against
+    lib/libhgemm_mi355x.so.  Both objects come from the content-hash cache, so a sweep over many
+    shapes pays the ~30 s torch-header compile of the shim exactly once."""
+    lib = build_library(verbose)
+    hdr = _headers_digest()
+    incs, libdirs = _torch_build_env()
+    shim_flags = ["-x", "c++", "-DUSE_ROCM=1", f"-DTORCH_EXTENSION_NAME={name}", "-DTORCH_API_INCLUDE_EXTENSION_H",
+                  "-D_GLIBCXX_USE_CXX11_ABI=1", "-Wno-deprecated-declarations", f"-I{PKG_DIR / 'pybind'}",
+                  *[f"-I{i}" for i in incs]]
+    shim_obj = compile_object(pybind_src, shim_flags, hdr, verbose)
+    kern_obj = compile_object(kernel_src, ["-x", "c++"], hdr, verbose)
+    base_dir.mkdir(parents=True, exist_ok=True)
+    out = base_dir / f"{name}.so"
+    stamp = base_dir / f".{name}.stamp"
+    want = f"{shim_obj.name} {kern_obj.name} {lib.stat().st_mtime_ns}"
+    if out.exists() and stamp.exists() and stamp.read_text() == want:
+        return out
+    tmp = base_dir / f"{name}.tmp{os.getpid()}.so"
+    _run([HIPCC, "-shared", "-fPIC", str(shim_obj), str(kern_obj), "-o", str(tmp), f"-L{LIB_DIR}", "-lhgemm_mi355x",
+          *[f"-L{d}" for d in libdirs], "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+          f"-L{ROCM / 'lib'}", "-lamdhip64", f"-Wl,-rpath,{LIB_DIR}", *[f"-Wl,-rpath,{d}" for d in libdirs]], verbose)
+    os.replace(tmp, out)
+    stamp.write_text(want)
+    return out
+
+
 def clean() -> None:
     for d in (BUILD, LIB_DIR, BIN_DIR):
         shutil.rmtree(d, ignore_errors=True)

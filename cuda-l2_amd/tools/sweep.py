@@ -1,0 +1,159 @@
+"""Shape-sweep driver: shards the (M,N,K) list across GPUs, evaluates every shape with the harness
+(eval_one_file.sh: correctness + 7 baselines), is resumable, and merges the per-shape summaries into
+the reference's eval_results CSV format plus per-shape TFLOP/s and the geomean speedups.
+
+The reference publishes only the merged CSVs (eval_results/*.csv) and has no driver; a single GEMM
+never spans GPUs, so multi-GPU = independent shards, no collective:
+
+    rank i of G evaluates shapes[i::G] on GPU i (one process per GPU), results meet on the filesystem.
+
+  python tools/sweep.py run   --out results --acc_precise fp32 --mode offline [--gpus 8] [--shapes-file f]
+  python tools/sweep.py merge --out results --acc_precise fp32 --mode offline
+Launched under torch.distributed.run it takes rank/world size from RANK / WORLD_SIZE / LOCAL_RANK.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent.parent
+if str(PKG_DIR) not in sys.path:
+    sys.path.insert(0, str(PKG_DIR))
+
+from tools.gen_shape_kernels import ACC_DIRS, grid_shapes  # noqa: E402
+
+CSV_COLUMNS = ["torch.matmul", "rocBLAS-tn", "rocBLAS-nn", "rocBLAS-max", "hipBLASLt-heuristic-tn",
+               "hipBLASLt-heuristic-nn", "hipBLASLt-heuristic-max", "hipBLASLt-auto-tuning-tn",
+               "hipBLASLt-auto-tuning-nn", "hipBLASLt-auto-tuning-max"]
+
+
+def shard(shapes: list[str], rank: int, world: int) -> list[str]:
+    """Round-robin partition: every shape costs ~the same wall time (fixed warm-up + benchmark seconds),
+    so shapes[rank::world] balances the ranks; the union over ranks is exactly `shapes`."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return shapes[rank::world]
+
+
+def flops(mnk: str) -> float:
+    m, n, k = map(int, mnk.split("_"))
+    return 2.0 * m * n * k
+
+
+def shape_dir(out: Path, acc: str, mode: str, mnk: str) -> Path:
+    return out / f"{acc}_{mode}" / mnk
+
+
+def is_done(out: Path, acc: str, mode: str, mnk: str) -> bool:
+    return (shape_dir(out, acc, mode, mnk) / "summary.json").exists()
+
+
+def run_shapes(shapes, args, rank: int, gpu: int) -> dict:
+    done = skipped = failed = 0
+    t0 = time.time()
+    for mnk in shapes:
+        if is_done(args.out, args.acc_precise, args.mode, mnk):
+            skipped += 1
+            continue
+        cmd = [str(PKG_DIR / "eval_one_file.sh"), "--mnk", mnk, "--acc_precise", args.acc_precise, "--device_type",
+               "mi355x", "--warmup_seconds", str(args.warmup_seconds), "--benchmark_seconds",
+               str(args.benchmark_seconds), "--base_dir", str(shape_dir(args.out, args.acc_precise, args.mode, mnk)),
+               "--gpu_device_id", str(gpu), "--mode", args.mode]
+        if args.mode == "server":
+            cmd += ["--target_qps", str(args.target_qps)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        log = shape_dir(args.out, args.acc_precise, args.mode, mnk) / "eval.log"
+        log.parent.mkdir(parents=True, exist_ok=True)
+        log.write_text(res.stdout + res.stderr)
+        if res.returncode == 0:
+            done += 1
+        else:
+            failed += 1
+            print(f"[rank {rank}] {mnk} FAILED (see {log})", flush=True)
+    return {"rank": rank, "gpu": gpu, "done": done, "skipped": skipped, "failed": failed, "seconds": time.time() - t0}
+
+
+def geomean(values) -> float:
+    vals = [v for v in values if v and v > 0 and math.isfinite(v)]
+    return math.exp(sum(math.log(v) for v in vals) / len(vals)) if vals else float("nan")
+
+
+def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
+    """-> report dict; writes eval_results-style CSV + tflops CSV under out/."""
+    rows, tf_rows = [], []
+    for mnk in shapes:
+        f = shape_dir(out, acc, mode, mnk) / "summary.json"
+        if not f.exists():
+            continue
+        table = {r["Baseline Method Name"]: r for r in json.loads(f.read_text())}
+        if not all(c in table for c in CSV_COLUMNS):
+            continue
+        rows.append([mnk] + [table[c]["Speedup"] for c in CSV_COLUMNS])
+        tf_rows.append([mnk, table["hipBLASLt-auto-tuning-max"]["CUDA-L2 TFLOPS"],
+                        table["hipBLASLt-auto-tuning-max"]["Baseline TFLOPS"], table["torch.matmul"]["Baseline TFLOPS"]])
+    name = f"cuda_l2_mi355x_{ACC_DIRS[acc]}_speedup_{mode}.csv"
+    with open(out / name, "w") as f:
+        f.write("mnk," + ",".join(CSV_COLUMNS) + "\n")
+        for r in rows:
+            f.write(r[0] + "," + ",".join(f"{v:.3f}" for v in r[1:]) + "\n")
+    with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_tflops_{mode}.csv", "w") as f:
+        f.write("mnk,cuda_l2_tflops,hipblaslt_autotune_max_tflops,torch_matmul_tflops\n")
+        for r in tf_rows:
+            f.write(f"{r[0]},{r[1]:.3f},{r[2]:.3f},{r[3]:.3f}\n")
+    report = {"shapes": len(rows), "csv": str(out / name)}
+    for i, c in enumerate(CSV_COLUMNS):
+        col = [r[1 + i] for r in rows]
+        report[f"geomean_speedup_vs_{c}"] = geomean(col)
+        report[f"mean_speedup_vs_{c}"] = sum(col) / len(col) if col else float("nan")
+    return report
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("command", choices=["run", "merge", "plan"])
+    ap.add_argument("--out", type=Path, required=True)
+    ap.add_argument("--acc_precise", choices=["fp16", "fp32"], default="fp32")
+    ap.add_argument("--mode", choices=["offline", "server"], default="offline")
+    ap.add_argument("--target_qps", type=float, default=100.0)
+    ap.add_argument("--warmup_seconds", type=float, default=5.0)
+    ap.add_argument("--benchmark_seconds", type=float, default=10.0)
+    ap.add_argument("--shapes", type=str, default="", help="comma separated M_N_K (default: the 1000-shape grid)")
+    ap.add_argument("--shapes-file", type=str, default="")
+    ap.add_argument("--gpus", type=int, default=None, help="world size when not launched by torch.distributed.run")
+    ap.add_argument("--rank", type=int, default=None)
+    args = ap.parse_args(argv)
+
+    if args.shapes_file:
+        shapes = [l.strip() for l in open(args.shapes_file) if l.strip()]
+    elif args.shapes:
+        shapes = [s for s in args.shapes.split(",") if s]
+    else:
+        shapes = grid_shapes()
+    world = int(os.environ.get("WORLD_SIZE", args.gpus or 1))
+    rank = int(os.environ.get("RANK", args.rank or 0))
+    gpu = int(os.environ.get("LOCAL_RANK", rank))
+    args.out.mkdir(parents=True, exist_ok=True)
+
+    if args.command == "plan":
+        for r in range(world):
+            mine = shard(shapes, r, world)
+            print(f"rank {r}: {len(mine)} shapes, {sum(map(flops, mine)):.3e} flop per pass")
+        return None
+    if args.command == "run":
+        status = run_shapes(shard(shapes, rank, world), args, rank, gpu)
+        (args.out / f"rank{rank}_status.json").write_text(json.dumps(status))
+        print(json.dumps(status))
+        return status
+    report = merge(args.out, args.acc_precise, args.mode, shapes)
+    print(json.dumps(report, indent=1))
+    return report
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+"""CPU tests of the host side: C-ABI library loads and exports everything include/hgemm_mi355x.h
+declares, planner / geometry table / error paths (no compute calls without a GPU), harness plumbing
+(BASELINE.json config 1: torch.matmul on the host through benchmarking_offline.py), summary rule,
+shape-file generator, sweep merge."""
+import ctypes
+import json
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+PKG = REPO / "cuda-l2_amd"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import build
+
+    so = build.build_library()
+    L = ctypes.CDLL(str(so))
+    L.hgemm_mi355x_config_name.restype = ctypes.c_char_p
+    L.hgemm_mi355x_strerror.restype = ctypes.c_char_p
+    L.hgemm_mi355x_version.restype = ctypes.c_char_p
+    L.hgemm_mi355x_model_us.restype = ctypes.c_double
+    L.hgemm_mi355x_model_us.argtypes = [ctypes.c_int] * 5
+    L.hgemm_mi355x_workspace_bytes.restype = ctypes.c_size_t
+    return L
+
+
+def header_functions():
+    text = (REPO / "include" / "hgemm_mi355x.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hgemm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/hgemm_mi355x.h but not exported"
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(PKG / "lib" / "libhgemm_mi355x.so")], capture_output=True,
+                        text=True, check=True).stdout
+    exported = set(re.findall(r" T (hgemm_[a-z0-9_]+)", nm))
+    assert set(names) <= exported
+    # nothing from the oracle may be linked into the product
+    assert "hgemm_oracle" not in nm
+    assert b"gfx950" in lib.hgemm_mi355x_version()
+
+
+def test_geometry_table(lib):
+    n = lib.hgemm_mi355x_num_configs()
+    assert n >= 24
+    seen = set()
+    for i in range(n):
+        name = lib.hgemm_mi355x_config_name(i).decode()
+        assert name not in seen
+        seen.add(name)
+        info = (ctypes.c_int * 8)()
+        assert lib.hgemm_mi355x_config_info(i, info) == 0
+        bm, bn, wm, wn, mi, nbuf, threads, lds = list(info)
+        assert threads == wm * wn * 64 and threads % 64 == 0      # 64-wide waves
+        assert lds <= 160 * 1024                                   # MI355X LDS per CU
+        assert bm % (wm * mi) == 0 and bn % (wn * mi) == 0
+        assert lib.hgemm_mi355x_config_by_name(name.encode()) == i
+    assert lib.hgemm_mi355x_config_name(n) is None
+    assert lib.hgemm_mi355x_config_by_name(b"no_such_geometry") == -1
+    assert lib.hgemm_mi355x_config_info(-1, (ctypes.c_int * 8)()) == -1
+
+
+@pytest.mark.parametrize("mnk", [(64, 4096, 64), (512, 4096, 4096), (4096, 4096, 4096), (64, 64, 16384),
+                                 (16384, 16384, 16384), (200, 136, 128)])
+def test_planner_returns_a_valid_plan(lib, mnk):
+    cfg, splits, group = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.hgemm_mi355x_plan(*mnk, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
+    assert 0 <= cfg.value < lib.hgemm_mi355x_num_configs()
+    assert 1 <= splits.value <= max(1, mnk[2] // 64) and group.value >= 1
+    assert lib.hgemm_mi355x_model_us(cfg.value, splits.value, *mnk) > 0
+    info = (ctypes.c_int * 8)()
+    lib.hgemm_mi355x_config_info(cfg.value, info)
+    assert info[0] <= 2 * max(mnk[0], 32) and info[1] <= 2 * max(mnk[1], 32)  # no tile that is mostly padding
+
+
+def test_planner_routes_unaligned_shapes_to_the_generic_kernel(lib):
+    cfg, splits, group = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.hgemm_mi355x_plan(100, 30, 50, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
+    assert cfg.value == -1 and splits.value == 1
+    assert lib.hgemm_mi355x_plan(0, 4, 4, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == -1
+
+
+def test_error_paths_do_not_touch_the_gpu(lib):
+    assert lib.hgemm_mi355x_fp32(None, None, None, None, 64, 64, 64, None) == -1
+    assert lib.hgemm_mi355x_launch(0, 1, 1, None, None, None, None, 64, 64, 64, 64, 64, 64, None) == -1
+    assert lib.hgemm_mi355x_launch(10 ** 6, 1, 1, ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                   64, 64, 64, 64, 64, 64, None) == -1
+    assert lib.hgemm_rocblas_nn(None, None, None, 64, 64, 64, 0, None) == -1
+    assert lib.hgemm_hipblaslt_autotune_nn(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 64, 64, 64, 0,
+                                           None) == -5  # NOT_READY: no find_best call yet
+    assert lib.hgemm_mi355x_strerror(-5).decode().startswith("baseline not")
+    assert lib.hgemm_mi355x_workspace_bytes(64, 128, 4) == 4 * 64 * 128 * 4
+    assert lib.hgemm_mi355x_workspace_bytes(64, 128, 1) == 0
+
+
+def test_cpu_plumbing_config_writes_the_reference_json_schema(tmp_path):
+    """BASELINE.json config 1: M=64 N=4096 K=64 via torch.matmul on the CPU (no GPU, no extension)."""
+    cmd = [sys.executable, "benchmarking_offline.py", "--mnk", "64_4096_64", "--acc_precise", "fp32", "--device_type",
+           "mi355x", "--warmup_seconds", "0.05", "--benchmark_seconds", "0.3", "--base_dir", str(tmp_path),
+           "--gpu_device_id", "0", "--perf_func", "matmul", "--device", "cpu", "--seed", "0"]
+    res = subprocess.run(cmd, cwd=PKG, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    data = json.loads((tmp_path / "benchmark_result_matmul.json").read_text())
+    assert data["records"]["version"] == "202511261845" and data["records"]["matmul"] > 0
+    assert data["device"] == "cpu" and data["cpu"]["os_cpu_count"] >= 1
+    lat = data["latency_ms"]["matmul"]
+    assert lat["p50"] <= lat["p99"]
+    # a GPU perf_func cannot run on the host path, and the extension refuses to load without a GPU
+    bad = subprocess.run(cmd[:-5] + ["--perf_func", "hgemm_cublas_tn", "--device", "cpu"], cwd=PKG, capture_output=True, text=True)
+    assert bad.returncode != 0
+
+
+def test_extension_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tools.utils import build_from_sources
+
+    with pytest.raises(RuntimeError, match="needs a visible MI355X"):
+        build_from_sources("64_4096_64", "fp32", "mi355x", "/tmp/never", False)
+
+
+def test_server_mode_sleep_and_tflops_formula(monkeypatch, tmp_path):
+    import benchmarking_server
+    import benchmarking_utils
+    import torch
+
+    slept = []
+    monkeypatch.setattr(benchmarking_server.time, "sleep", lambda s: slept.append(s))
+    args = benchmarking_server.build_arg_parser().parse_args(
+        ["--mnk", "32_48_64", "--acc_precise", "fp32", "--device_type", "mi355x", "--warmup_seconds", "0.02",
+         "--benchmark_seconds", "0.1", "--base_dir", str(tmp_path), "--gpu_device_id", "0", "--perf_func", "matmul",
+         "--device", "cpu", "--target_qps", "1000", "--seed", "1"])
+    result = benchmarking_server.offline.run(args, extra={"target_qps": args.target_qps})
+    assert result["mode"] == "server" and result["target_qps"] == 1000 and len(slept) >= result["iterations"]
+    assert all(s >= 0 for s in slept)
+    rec = benchmarking_utils.run_all_perf_funcs_once(perf_func_list=[torch.matmul], m=32, n=48, k=64, acc_precise="fp32",
+                                                     device_type="mi355x", padding_m=0, padding_k=0, padding_n=0, device="cpu")
+    assert rec["matmul"] == pytest.approx(2 * 32 * 48 * 64 * 1e-12 * 1000 / rec["matmul_ms"])
+
+
+def test_summary_max_row_is_the_stronger_baseline(tmp_path):
+    import summarize_result
+
+    def put(name, base, ours):
+        (tmp_path / f"benchmark_result_{name}.json").write_text(json.dumps(
+            {"records": {name: base, "cuda_l2_mi355x_fp32": ours, "version": "x"}}))
+
+    put("hgemm_cublas_tn", 100.0, 120.0)              # speedup 1.2
+    put("hgemm_cublas_nn", 80.0, 118.0)               # speedup 1.475 -> -max must pick tn (lower speedup)
+    put("hgemm_cublaslt_heuristic_tn", 100.0, 90.0)
+    put("hgemm_cublaslt_heuristic_nn", 110.0, 91.0)   # 0.827 -> -max picks nn
+    put("hgemm_cublaslt_auto_tuning_tn", 50.0, 100.0)
+    put("hgemm_cublaslt_auto_tuning_nn", 50.0, 99.0)
+    put("matmul", 60.0, 120.0)
+    rows = {r["Baseline Method Name"]: r for r in summarize_result.summarize(tmp_path, "cuda_l2_mi355x_fp32")}
+    assert list(rows) == summarize_result.NAME_ORDER
+    assert rows["rocBLAS-max"]["Baseline TFLOPS"] == 100.0 and rows["rocBLAS-max"]["Speedup"] == pytest.approx(1.2)
+    assert rows["hipBLASLt-heuristic-max"]["Baseline TFLOPS"] == 110.0
+    assert rows["hipBLASLt-auto-tuning-max"]["Speedup"] == pytest.approx(1.98)
+    assert rows["torch.matmul"]["Speedup"] == pytest.approx(2.0)
+
+
+def test_shape_file_generator_and_sources(tmp_path):
+    from tools import gen_shape_kernels as gen
+    from tools.utils import compute_padding, get_build_sources, kernel_source_path
+
+    shapes = gen.grid_shapes()
+    assert len(shapes) == 1000 and shapes[0] == "64_64_64" and "12288_16384_64" in shapes
+    for mnk in ["64_4096_64", "512_4096_4096", "4096_4096_4096"]:       # the BASELINE.json shapes are committed
+        for acc in ("fp16", "fp32"):
+            text = kernel_source_path(mnk, acc, "mi355x").read_text()
+            assert "HGEMM_MI355X_SHAPE_ENTRY(" + ", ".join(mnk.split("_")) in text
+            assert compute_padding(*map(int, mnk.split("_")), text) == (0, 0, 0)
+    srcs = get_build_sources("64_4096_64", "fp16", "mi355x")
+    assert srcs[-1] == "pybind/hgemm_mi355x_fp16.cc" and "F16F16F16F16" in srcs[-2]
+    for s in srcs:
+        assert (PKG / s).exists()
+    with pytest.raises(ValueError):
+        get_build_sources("64_4096_64", "bf16", "mi355x")
+    name, splits, group = gen.model_plan(4096, 4096, 4096)
+    assert splits >= 1 and group >= 1 and name
+
+
+def test_sweep_shard_and_merge(tmp_path):
+    from tools import sweep
+
+    shapes = [f"{64 * (i + 1)}_64_64" for i in range(11)]
+    parts = [sweep.shard(shapes, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == sorted(shapes) and max(map(len, parts)) - min(map(len, parts)) <= 1
+    with pytest.raises(ValueError):
+        sweep.shard(shapes, 4, 4)
+    for mnk, sp in [(shapes[0], 1.5), (shapes[1], 0.5)]:
+        d = sweep.shape_dir(tmp_path, "fp32", "offline", mnk)
+        d.mkdir(parents=True)
+        rows = [{"Baseline Method Name": c, "Baseline TFLOPS": 10.0, "CUDA-L2 TFLOPS": 10.0 * sp, "Speedup": sp}
+                for c in sweep.CSV_COLUMNS]
+        (d / "summary.json").write_text(json.dumps(rows))
+    assert sweep.is_done(tmp_path, "fp32", "offline", shapes[0]) and not sweep.is_done(tmp_path, "fp32", "offline", shapes[2])
+    rep = sweep.merge(tmp_path, "fp32", "offline", shapes)
+    assert rep["shapes"] == 2
+    assert rep["geomean_speedup_vs_hipBLASLt-auto-tuning-max"] == pytest.approx((1.5 * 0.5) ** 0.5)
+    assert rep["mean_speedup_vs_torch.matmul"] == pytest.approx(1.0)
+    csv = Path(rep["csv"]).read_text().splitlines()
+    assert csv[0].startswith("mnk,torch.matmul,rocBLAS-tn") and csv[1].startswith(shapes[0] + ",1.500")
