@@ -99,7 +99,8 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   const int ksteps = (K / splits + BK - 1) / BK;
   // MFMA efficiency falls with the wave tile's operand reuse (LDS bytes per flop).
   const double reuse = (double)tm * tn / (tm + tn);
-  const double eff = 0.62 * std::min(1.0, reuse / 42.0) * (e.mi == 32 ? 1.05 : 1.0);
+  // measured on MI355X: the 32x32x16 MFMA variants trail the 16x16x32 ones by 5-15 % in this structure
+  const double eff = 0.62 * std::min(1.0, reuse / 42.0) * (e.mi == 32 ? 0.88 : 1.0);
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
   const double step_lat = (e.nbuf >= 3 ? 0.22 : 0.40);  // barrier + LDS-DMA round trip floor
   const double main_us = rounds * (1.2 + ksteps * std::max(step_tp, step_lat));

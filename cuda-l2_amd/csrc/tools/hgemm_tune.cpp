@@ -236,6 +236,18 @@ static int cmd_check(const std::vector<Shape>& shapes) {
 // ------------------------------------------------------------------------------------------------
 static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, double keep_ratio, int max_cand,
                     bool baselines, bool sweep_group) {
+  // resumable: shapes already present in --out are skipped
+  std::vector<std::string> have;
+  if (out_path) {
+    std::ifstream prev(out_path);
+    std::string line;
+    while (std::getline(prev, line)) {
+      const size_t p0 = line.find("\"mnk\": \"");
+      if (p0 == std::string::npos) continue;
+      const size_t p1 = line.find('"', p0 + 8);
+      have.push_back(line.substr(p0 + 8, p1 - p0 - 8));
+    }
+  }
   FILE* out = out_path ? fopen(out_path, "a") : stdout;
   if (!out) { perror("open --out"); return 2; }
   hipEvent_t e0, e1;
@@ -246,6 +258,9 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     hgemm_hipblaslt_heuristic_init();
   }
   for (const Shape& sh : shapes) {
+    char key[64];
+    snprintf(key, sizeof key, "%d_%d_%d", sh.M, sh.N, sh.K);
+    if (std::find(have.begin(), have.end(), std::string(key)) != have.end()) continue;
     const double flops = 2.0 * sh.M * sh.N * (double)sh.K;
     const size_t set_bytes = 2 * ((size_t)sh.M * sh.K + (size_t)sh.N * sh.K * (baselines ? 2 : 1) + (size_t)sh.M * sh.N);
     // rotate enough buffer sets to exceed L2 + MALL (~288 MiB), capped at 6 GiB total

@@ -1,0 +1,104 @@
+"""GPU tests of the drop-in surface: the `hgemm_lib` torch extension (15 names), the reference's
+correctness-check flow and the offline/server benchmark scripts, for BASELINE.json's 64x4096x64."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = Path(__file__).resolve().parent.parent
+PKG = REPO / "cuda-l2_amd"
+
+NAMES = ["init_cublas_handle", "destroy_cublas_handle", "hgemm_cublas_nn", "hgemm_cublas_tn", "init_cublaslt_handle_v1",
+         "destroy_cublaslt_handle_v1", "hgemm_cublaslt_heuristic_nn", "hgemm_cublaslt_heuristic_tn",
+         "init_cublaslt_handle_v2", "destroy_cublaslt_handle_v2", "find_best_algo_nn_v2_torch", "find_best_algo_tn_v2_torch",
+         "hgemm_cublaslt_auto_tuning_nn", "hgemm_cublaslt_auto_tuning_tn"]
+
+
+@pytest.fixture(scope="module")
+def kernel(tmp_path_factory):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    from harness_common import load_kernel
+
+    return load_kernel("64_4096_64", "fp32", "mi355x", str(tmp_path_factory.mktemp("ext")))
+
+
+def test_extension_exports_the_reference_surface(kernel):
+    for name in NAMES + ["cuda_l2_mi355x_fp32"]:
+        assert callable(getattr(kernel.module, name))
+    assert kernel.cuda_l2_func.__name__ == "cuda_l2_mi355x_fp32"   # the harness keys on __name__
+    assert kernel.padding == (0, 0, 0)
+    loaded = Path(kernel.module.__file__)
+    assert loaded.name == "hgemm_lib.so"
+
+
+def test_entry_point_semantics_and_errors(kernel):
+    from tools.utils import as_col_major
+
+    f = kernel.cuda_l2_func
+    a = torch.randn(64, 64, dtype=torch.half, device="cuda")
+    b = torch.randn(64, 4096, dtype=torch.half, device="cuda")
+    c = torch.full((64, 4096), float("nan"), dtype=torch.half, device="cuda")
+    assert f(a, b, as_col_major(b), c) is None                        # returns None, writes in place
+    torch.cuda.synchronize()
+    ref = a.float() @ b.float()
+    assert ((c.float() - ref).abs().max() / ref.abs().max()).item() <= 1e-3
+    with pytest.raises(RuntimeError, match="values must be torch::kHalf"):
+        f(a.float(), b, as_col_major(b), c)
+    with pytest.raises(RuntimeError, match="Tensor size mismatch"):
+        kernel.module.hgemm_cublas_nn(a, b, as_col_major(b), torch.zeros(64, 64, dtype=torch.half, device="cuda"))
+    # another shape through the same extension still computes correctly (library planner fall-back)
+    a2 = torch.randn(128, 256, dtype=torch.half, device="cuda")
+    b2 = torch.randn(256, 192, dtype=torch.half, device="cuda")
+    c2 = torch.empty(128, 192, dtype=torch.half, device="cuda")
+    f(a2, b2, as_col_major(b2), c2)
+    torch.cuda.synchronize()
+    ref2 = a2.float() @ b2.float()
+    assert ((c2.float() - ref2).abs().max() / ref2.abs().max()).item() <= 1e-3
+
+
+def test_zero_one_correctness_flow_passes(kernel):
+    import zero_one_correctness_check as zo
+
+    success, message, result = zo.run_correctness_check(kernel, 64, 4096, 64, num_iterations=5, max_seconds=30)
+    assert success, message
+    assert result["avg_cuda_l2_mi355x_fp32_diff"] == 0.0 and result["num_iterations"] == 5
+    for name in ("hgemm_cublas_tn", "hgemm_cublaslt_heuristic_nn", "hgemm_cublaslt_auto_tuning_tn", "matmul"):
+        assert result[f"avg_{name}_diff"] == 0.0
+    ok, msg = zo.judge({"avg_cuda_l2_mi355x_fp32_diff": 1.0, "avg_matmul_diff": 0.0}, "cuda_l2_mi355x_fp32", True)
+    assert not ok and "exceeds 0" in msg
+    assert zo.judge({"avg_cuda_l2_mi355x_fp32_diff": 0.0, "avg_matmul_diff": 0.0}, "cuda_l2_mi355x_fp32", False) == (
+        False, "memory overflow detected.")
+
+
+def test_offline_and_server_scripts_and_summary(tmp_path):
+    base = ["--mnk", "64_4096_64", "--acc_precise", "fp32", "--device_type", "mi355x", "--base_dir", str(tmp_path),
+            "--gpu_device_id", "0", "--warmup_seconds", "0.3", "--benchmark_seconds", "0.7"]
+    for func in ("hgemm_cublas_tn", "hgemm_cublas_nn", "hgemm_cublaslt_heuristic_tn", "hgemm_cublaslt_heuristic_nn",
+                 "hgemm_cublaslt_auto_tuning_tn", "hgemm_cublaslt_auto_tuning_nn"):
+        res = subprocess.run([sys.executable, "benchmarking_offline.py", *base, "--perf_func", func], cwd=PKG,
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    res = subprocess.run([sys.executable, "benchmarking_server.py", *base, "--perf_func", "matmul", "--target_qps", "200"],
+                         cwd=PKG, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    rec = json.loads((tmp_path / "benchmark_result_matmul.json").read_text())
+    assert rec["mode"] == "server" and rec["target_qps"] == 200
+    assert rec["records"]["cuda_l2_mi355x_fp32"] > 0 and rec["latency_ms"]["cuda_l2_mi355x_fp32"]["p99"] > 0
+    res = subprocess.run([sys.executable, "summarize_result.py", "--base_dir", str(tmp_path), "--acc_precise", "fp32",
+                          "--device_type", "mi355x"], cwd=PKG, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-1500:]
+    rows = json.loads((tmp_path / "summary.json").read_text())
+    assert [r["Baseline Method Name"] for r in rows][-1] == "hipBLASLt-auto-tuning-max" and len(rows) == 10
+
+
+def test_smoke_entry():
+    sys.path.insert(0, str(REPO))
+    import __graft_entry__
+
+    __graft_entry__.smoke()

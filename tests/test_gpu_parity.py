@@ -1,0 +1,241 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI of
+libhgemm_mi355x.so, against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for the reference's {0,1}/{0,0,1} inputs wherever |truth| <= 2047 (the reference's own
+pass rule, zero_one_correctness_check.py:263-268); max|C-ref|/max|ref| <= 1e-3 for N(0,1) inputs in
+BOTH accumulate modes (BASELINE.json allows 1e-2 for fp16-acc; CDNA4 accumulates in fp32 either way)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+REL_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gpu_common
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (torch.cuda.is_available() is False)")
+    return gpu_common
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import hgemm_oracle
+
+    return hgemm_oracle
+
+
+def _golden_cases():
+    return json.loads((GOLDEN / "harness_golden.json").read_text())["cases"]
+
+
+@pytest.mark.parametrize("entry", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", _golden_cases())
+def test_golden_fixtures(g, oracle, case, entry):
+    npz = np.load(GOLDEN / "hgemm_golden.npz")
+    a, b, truth = npz[case + "_a"], npz[case + "_b"], npz[case + "_truth"]
+    got = g.gemm(a, b, entry)
+    if case.startswith("zo_"):
+        assert oracle.masked_max_diff(got, truth) == 0.0
+    else:
+        assert oracle.relative_error(got, npz[case + "_f32"]) <= REL_TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64), (7, 12, 64), (64, 64, 64), (200, 136, 128), (320, 448, 512),
+                                   (1000, 520, 192), (33, 17, 40), (65, 30, 100), (5, 4, 8)])
+def test_ragged_and_unaligned_shapes_match_oracle(g, oracle, shape):
+    """Edge tiles are predicated in-kernel (no harness padding); K % 64 != 0 or N % 4 != 0 take the generic kernel."""
+    m, n, k = shape
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_f32acc(a, b)
+    for entry in ("fp32", "fp16"):
+        got = g.gemm(a, b, entry)
+        assert not np.isnan(got).any(), "an output element was never written"
+        assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
+
+
+def test_every_geometry_and_split_k_is_exact(g, oracle):
+    """All kernel instantiations x split-K factors on one ragged shape, explicit plans."""
+    m, n, k = 328, 456, 1024
+    rng = np.random.default_rng(11)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a, b)
+    for cid, name in enumerate(g.config_names()):
+        for splits, group in [(1, 1), (1, 3), (2, 1), (5, 1), (16, 2)]:
+            got = g.gemm(a, b, plan=(cid, splits, group))
+            assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, splits, group)
+
+
+def test_asymmetric_identity_catches_transposes(g):
+    """A = I, B asymmetric: C must equal B bit for bit (an MFMA C-layout row/col swap would not)."""
+    n = 512
+    a = np.eye(n, dtype=np.float16)
+    b = (np.arange(n * 384, dtype=np.float32).reshape(n, 384) % 251 - 125).astype(np.float16)
+    assert not np.array_equal(b[:384, :384], b[:384, :384].T)
+    for cid in range(len(g.config_names())):
+        got = g.gemm(a, b, plan=(cid, 1, 2))
+        assert np.array_equal(got.view(np.uint16), b.view(np.uint16)), g.config_names()[cid]
+
+
+def test_guard_bars_stay_intact(g, oracle):
+    """Operands are views into flat buffers with 16384-element bars either side (reference
+    zero_one_correctness_check.py:98-150): no byte outside the operand windows may change."""
+    L = g.lib()
+    bar = 16384
+    m, n, k = 200, 136, 256
+    rng = np.random.default_rng(5)
+    a_np, b_np = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_f32acc(a_np, b_np)
+
+    def guarded(x):
+        flat = torch.randn(x.size + 2 * bar, dtype=torch.half, device="cuda")
+        flat[bar:bar + x.size] = torch.from_numpy(x.reshape(-1)).cuda()
+        return flat, flat.clone()
+
+    fa, ca = guarded(a_np)
+    fb, cb = guarded(b_np)
+    fbt, cbt = guarded(np.ascontiguousarray(b_np.T))
+    fc, cc = guarded(np.zeros((m, n), dtype=np.float16))
+    esz = 2
+    for cid in [-1] + list(range(len(g.config_names()))):
+        for splits in (1, 4):
+            fc[bar:bar + m * n] = float("nan")
+            st = L.hgemm_mi355x_launch(cid, splits, 1, fa.data_ptr() + bar * esz, fb.data_ptr() + bar * esz,
+                                       fbt.data_ptr() + bar * esz, fc.data_ptr() + bar * esz, m, n, k, k, k, n, g.stream())
+            assert st == 0
+            torch.cuda.synchronize()
+            out = fc[bar:bar + m * n].view(m, n).cpu().numpy()
+            assert np.array_equal(out.view(np.uint16), truth.view(np.uint16))
+            for flat, clone in ((fa, ca), (fb, cb), (fbt, cbt)):
+                assert torch.equal(flat, clone)
+            assert torch.equal(fc[:bar], cc[:bar]) and torch.equal(fc[-bar:], cc[-bar:])
+
+
+def test_unaligned_pointers_fall_back_to_the_generic_kernel(g, oracle):
+    L = g.lib()
+    m, n, k = 64, 64, 64
+    rng = np.random.default_rng(9)
+    a_np, b_np = oracle.zero_one_inputs(m, n, k, rng)
+    flat = torch.zeros(m * k + 1, dtype=torch.half, device="cuda")
+    flat[1:] = torch.from_numpy(a_np.reshape(-1)).cuda()          # A starts 2 bytes off a 16-byte boundary
+    b = torch.from_numpy(b_np).cuda()
+    bt = b.t().contiguous()
+    c = torch.full((m, n), float("nan"), dtype=torch.half, device="cuda")
+    assert L.hgemm_mi355x_fp32(flat.data_ptr() + 2, b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, g.stream()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy().view(np.uint16), oracle.truth_f32acc(a_np, b_np).view(np.uint16))
+
+
+@pytest.mark.parametrize("mnk,entry", [((64, 4096, 64), "fp32"), ((512, 4096, 4096), "fp32"), ((4096, 4096, 4096), "fp16"),
+                                       ((64, 64, 16384), "fp32"), ((12288, 64, 8192), "fp32"), ((64, 16384, 12288), "fp16")])
+def test_baseline_sizes_zero_one_exact(g, mnk, entry):
+    """BASELINE.json sizes (and large-K / 12288 / 16384 cases), the reference's rule end to end:
+    0/1 operands, truth = fp32 matmul on the CPU rounded to fp16, masked above 2047, diff must be 0."""
+    from oracle import hgemm_oracle as oracle
+
+    m, n, k = mnk
+    rng = np.random.default_rng(m + n + k)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)           # {0,0,1} automatically beyond 8192
+    truth = torch.matmul(torch.from_numpy(a).float(), torch.from_numpy(b).float()).half().numpy()
+    got = g.gemm(a, b, entry)
+    assert oracle.masked_max_diff(got, truth) == 0.0
+    assert (np.abs(truth.astype(np.float32)) <= 2047).mean() > 0.4  # the mask must leave real coverage
+
+
+def test_full_size_linearity_property(g):
+    """Size-independent property at 512x4096x4096: for 0/1 B split into disjoint supports B1 + B2,
+    C(A,B) == C(A,B1) + C(A,B2) exactly (all sums are integers <= 2047 here)."""
+    m, n, k = 512, 4096, 4096
+    rng = np.random.default_rng(2)
+    a = (rng.random((m, k)) < 0.25).astype(np.float16)
+    b = (rng.random((k, n)) < 0.25).astype(np.float16)
+    sel = rng.random((k, n)) < 0.5
+    c = g.gemm(a, b).astype(np.float32)
+    c1 = g.gemm(a, (b * sel).astype(np.float16)).astype(np.float32)
+    c2 = g.gemm(a, (b * ~sel).astype(np.float16)).astype(np.float32)
+    assert c.max() <= 2047 and np.array_equal(c, c1 + c2)
+
+
+def test_randn_tolerance_at_4096_cubed(g, oracle):
+    """N(0,1) operands (what the benchmark feeds): relative error vs fp32 on a 192-row sample of C."""
+    n = 4096
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((n, n), dtype=np.float32).astype(np.float16)
+    b = rng.standard_normal((n, n), dtype=np.float32).astype(np.float16)
+    rows = rng.choice(n, 192, replace=False)
+    ref = a[rows].astype(np.float32) @ b.astype(np.float32)
+    for entry in ("fp32", "fp16"):
+        got = g.gemm(a, b, entry)
+        assert oracle.relative_error(got[rows], ref) <= REL_TOL
+    again = g.gemm(a, b, "fp32")
+    assert np.array_equal(again.view(np.uint16), g.gemm(a, b, "fp32").view(np.uint16))  # run-to-run identical
+
+
+def test_split_k_is_deterministic_and_within_tolerance(g, oracle):
+    m, n, k = 128, 256, 16384
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((m, k), dtype=np.float32).astype(np.float16)
+    b = rng.standard_normal((k, n), dtype=np.float32).astype(np.float16)
+    ref = a.astype(np.float32) @ b.astype(np.float32)
+    cid = g.config_names().index("t64x64_w2x2_m16_s4")
+    outs = [g.gemm(a, b, plan=(cid, 16, 1)) for _ in range(3)]
+    assert all(np.array_equal(outs[0].view(np.uint16), o.view(np.uint16)) for o in outs[1:])
+    assert oracle.relative_error(outs[0], ref) <= REL_TOL
+
+
+def test_baselines_agree_with_oracle(g, oracle):
+    """rocBLAS / hipBLASLt wrappers (the speed-up denominators) compute the same product."""
+    L = g.lib()
+    m, n, k = 256, 512, 1024
+    rng = np.random.default_rng(8)
+    a_np, b_np = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a_np, b_np)
+    a = torch.from_numpy(a_np).cuda()
+    b = torch.from_numpy(b_np).cuda()
+    bt = b.t().contiguous()
+    assert L.hgemm_rocblas_init() == 0 and L.hgemm_hipblaslt_heuristic_init() == 0 and L.hgemm_hipblaslt_autotune_init() == 0
+    assert L.hgemm_hipblaslt_autotune_find_best_nn(m, n, k, 0) == 0 and L.hgemm_hipblaslt_autotune_find_best_tn(m, n, k, 0) == 0
+    assert L.hgemm_hipblaslt_autotune_candidates(0) >= 1 and L.hgemm_hipblaslt_autotune_candidates(1) >= 1
+    import ctypes
+
+    for name, second in [("hgemm_rocblas_nn", b), ("hgemm_rocblas_tn", bt), ("hgemm_hipblaslt_heuristic_nn", b),
+                         ("hgemm_hipblaslt_heuristic_tn", bt), ("hgemm_hipblaslt_autotune_nn", b),
+                         ("hgemm_hipblaslt_autotune_tn", bt)]:
+        fn = getattr(L, name)
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        for acc in (0, 1):
+            if "autotune" in name and acc == 1:
+                continue  # algorithm was selected for acc=0 only
+            c = torch.full((m, n), float("nan"), dtype=torch.half, device="cuda")
+            assert fn(a.data_ptr(), second.data_ptr(), c.data_ptr(), m, n, k, acc, g.stream()) == 0, (name, acc)
+            torch.cuda.synchronize()
+            assert oracle.masked_max_diff(c.cpu().numpy(), truth) == 0.0, (name, acc)
+    # an autotuned entry point refuses a problem it was not tuned for
+    c = torch.zeros((m, n), dtype=torch.half, device="cuda")
+    assert L.hgemm_hipblaslt_autotune_nn(a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k // 2, 0, g.stream()) == -5
+    L.hgemm_rocblas_destroy(); L.hgemm_hipblaslt_heuristic_destroy(); L.hgemm_hipblaslt_autotune_destroy()
+
+
+def test_fill_normal_statistics(g):
+    L = g.lib()
+    import ctypes
+
+    L.hgemm_fill_normal_f16.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_void_p]
+    x = torch.empty(1 << 20, dtype=torch.half, device="cuda")
+    assert L.hgemm_fill_normal_f16(x.data_ptr(), x.numel(), 42, g.stream()) == 0
+    torch.cuda.synchronize()
+    xf = x.float()
+    assert abs(xf.mean().item()) < 0.01 and abs(xf.std().item() - 1.0) < 0.01
+    y = torch.empty_like(x)
+    L.hgemm_fill_normal_f16(y.data_ptr(), y.numel(), 42, g.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
