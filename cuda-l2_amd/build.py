@@ -26,7 +26,9 @@ CSRC = PKG_DIR / "csrc"
 INCLUDE = REPO_DIR / "include"
 BUILD = PKG_DIR / "build"
 OBJ = BUILD / "obj"
-LIB_DIR = PKG_DIR / "lib"
+# experiment builds: HGEMM_LIB_SUFFIX=nt HGEMM_EXTRA_HIPFLAGS="-DHGEMM_DMA_AUX=2" python build.py -> lib_nt/
+_SUFFIX = os.environ.get("HGEMM_LIB_SUFFIX", "")
+LIB_DIR = PKG_DIR / ("lib_" + _SUFFIX if _SUFFIX else "lib")
 BIN_DIR = PKG_DIR / "bin"
 ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
 HIPCC = str(ROCM / "bin" / "hipcc")
@@ -42,7 +44,7 @@ LIB_SOURCES = [
     "hgemm_baselines.hip",
 ]
 
-HIP_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+HIP_FLAGS = os.environ.get("HGEMM_EXTRA_HIPFLAGS", "").split() + [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-Wno-unused-result", "-Wno-unused-value", "-DROCBLAS_NO_DEPRECATED_WARNINGS", "-D__HIP_PLATFORM_AMD__"]
 
 

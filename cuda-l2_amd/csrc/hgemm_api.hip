@@ -79,10 +79,18 @@ constexpr double kBoundaryUs   = 1.8;    // dependent kernel boundary (split-K c
 constexpr double kHbmBytesUs   = 5.0e6;  // ~5 TB/s sustained for mixed read/write
 constexpr double kCuFlopUs     = 4069.0 * 2000.0;  // fp16 MFMA flop per CU per us at ~2.0 GHz
 
-int default_group_m(int tiles_m, int tiles_n) {
-  const int per_xcd = std::max(1, (tiles_m * tiles_n + NUM_XCD - 1) / NUM_XCD);
+// Raster group height.  What matters for L2 reuse is the set of tiles an XCD runs CONCURRENTLY
+// (32 CUs x workgroups per CU), not all the tiles it will ever get: consecutive logical ids fill a
+// column of `g` tiles, so `c` concurrent tiles touch g A-panels and c/g B-panels; panel bytes are
+// g*BM + (c/g)*BN rows, minimal at g = sqrt(c*BN/BM).  (Measured at 8192^3: g=4 1289 TF, g=16 1211.)
+int default_group_m(const KernelEntry& e, int tiles_m, int tiles_n) {
+  const int nw = e.wm * e.wn;
+  const int wg_per_cu = std::max(1, std::min(160 * 1024 / e.lds_bytes, std::max(1, 8 / nw)));
+  const long per_xcd_total = std::max<long>(1, ((long)tiles_m * tiles_n + NUM_XCD - 1) / NUM_XCD);
+  const double conc = (double)std::min<long>(per_xcd_total, 32L * wg_per_cu);
+  const double ideal = std::sqrt(conc * e.bn / e.bm);
   int g = 1;
-  while (g * g * 4 <= per_xcd * 2 && g * 2 <= tiles_m) g *= 2;  // ~sqrt(per_xcd / 2), power of two
+  while (g * 2 <= ideal * 1.42 && g * 2 <= tiles_m) g *= 2;   // nearest power of two
   return std::max(1, std::min(g, tiles_m));
 }
 
@@ -130,7 +138,7 @@ void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   }
   *cfg = bc; *splits = bs;
   const KernelEntry& e = g_kernel_table[bc];
-  *group_m = default_group_m((M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
+  *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
 }
 
 bool mfma_path_ok(const void* a, const void* bt, const void* c, int M, int N, int K, int lda,
@@ -198,6 +206,12 @@ int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* gro
 double hgemm_mi355x_model_us(int config_id, int splits, int M, int N, int K) {
   if (config_id < 0 || config_id >= g_num_kernels || splits < 1 || M <= 0 || N <= 0 || K <= 0) return -1.0;
   return model_us(g_kernel_table[config_id], M, N, K, splits);
+}
+
+int hgemm_mi355x_default_group(int config_id, int M, int N) {
+  if (config_id < 0 || config_id >= g_num_kernels || M <= 0 || N <= 0) return 1;
+  const KernelEntry& e = g_kernel_table[config_id];
+  return default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
 }
 
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits) {

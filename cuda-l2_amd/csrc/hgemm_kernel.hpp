@@ -44,6 +44,12 @@ constexpr int BK        = 64;       // K elements per pipeline stage
 constexpr int ROW_BYTES = BK * 2;   // one tile row in LDS = 128 B
 constexpr int NUM_XCD   = 8;
 
+// cache-policy bits of the LDS-DMA loads (buffer_load ... lds aux operand: 1 = sc0, 2 = nt, 16 = sc1).
+// 0 = default policy; other values are build-time experiments (build.py HGEMM_EXTRA_HIPFLAGS).
+#ifndef HGEMM_DMA_AUX
+#define HGEMM_DMA_AUX 0
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 struct GemmArgs {
@@ -129,6 +135,36 @@ __device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN
 template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, class ACC>
 __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& tc, int wave_m,
                                            int wave_n, int lane, ACC (&acc)[FM][FN]) {
+  // Wide path (fp16 output, 16x16 MFMA tiles, FN even): v_permlane16_swap exchanges the odd 16-lane
+  // rows of tile j with the even rows of tile j+1, after which every lane owns 8 consecutive N
+  // (16 bytes) of its C row: half the store instructions, 64 contiguous bytes per row per store.
+  //   row q = lane >> 4 ends up with n = 16*(j + (q & 1)) + 8*(q >> 1) + 0..7
+  if constexpr (!SPLITK && MI == 16 && (FN % 2 == 0)) {
+    const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    if (wide) {
+      const int q = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = tc.m0 + wave_m * TM + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+          using h2 = __attribute__((ext_vector_type(2))) _Float16;
+          const h2 a01 = {(f16)acc[i][j][0], (f16)acc[i][j][1]}, a23 = {(f16)acc[i][j][2], (f16)acc[i][j][3]};
+          const h2 b01 = {(f16)acc[i][j + 1][0], (f16)acc[i][j + 1][1]}, b23 = {(f16)acc[i][j + 1][2], (f16)acc[i][j + 1][3]};
+          const auto r0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, b01), false, false);
+          const auto r1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a23), __builtin_bit_cast(unsigned, b23), false, false);
+          const int n = tc.n0 + wave_n * TN + 16 * (j + (q & 1)) + 8 * (q >> 1);
+          if (m < g.M && n < g.N) {
+            using u4 = __attribute__((ext_vector_type(4))) unsigned;
+            const u4 o = {r0[0], r1[0], r0[1], r1[1]};
+            *(u4*)(g.C + (size_t)m * g.ldc + n) = o;
+          }
+        }
+      }
+      return;
+    }
+  }
   const int lm = (MI == 16) ? (lane & 15) : (lane & 31);
   const int ln = (MI == 16) ? ((lane >> 4) * 4) : ((lane >> 5) * 4);
   constexpr int NQ = (MI == 16) ? 1 : 4;
@@ -176,9 +212,9 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsA, __amdgpu_
     if (CFG::NI % CFG::NW == 0 || i < CFG::NI) {
       lds_void_t* dst = (lds_void_t*)(lds_stage + i * 1024);
       if (i < CFG::NI_A)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[j], kbyte, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[j], kbyte, 0, HGEMM_DMA_AUX);
       else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[j], kbyte, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[j], kbyte, 0, HGEMM_DMA_AUX);
     }
   }
 }

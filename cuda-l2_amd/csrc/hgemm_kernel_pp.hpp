@@ -76,9 +76,9 @@ __device__ __forceinline__ void pp_mfma_phase(f32x4 (&acc)[CFG::FM][CFG::FN], co
           const int piece = wave + p * CFG::NW;  // wave-uniform
           lds_void_t* dst = (lds_void_t*)(lds_slot + piece * 1024);
           if (piece < CFG::NIH_A)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
           else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
         }
       }
     }
@@ -93,9 +93,9 @@ __device__ __forceinline__ void pp_stage_half(__amdgpu_buffer_rsrc_t rsA, __amdg
     const int piece = wave + p * CFG::NW;
     lds_void_t* dst = (lds_void_t*)(lds_slot + piece * 1024);
     if (piece < CFG::NIH_A)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
   }
 }
 

@@ -45,6 +45,15 @@ struct CfgSP : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
 __device__ __forceinline__ void sp_mfma(f32x4& acc, const f16x8& a, const f16x8& b) {
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// Last MFMA of an interval.  hipcc cannot see the MFMAs inside the asm statements, so it pads
+// nothing between them and its own readers of their results -- and after the K loop it does place
+// accumulator copies (v_accvgpr_read/mov from live-range splitting) straight behind the final MFMA;
+// observed: element 0 of the last accumulator one K-slice stale.  The required MFMA-result ->
+// reader wait states (8-pass XDL) therefore travel inside the statement itself: 16 states behind the
+// last MFMA also cover its predecessors, which are at least one MFMA issue older each.
+__device__ __forceinline__ void sp_mfma_last(f32x4& acc, const f16x8& a, const f16x8& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
+}
 
 // One interval: FM*FN MFMAs on the current fragment set (af, bf) with, in the issue slots between
 // them, (a) the FM+FN fragment reads of the NEXT K=32 slice into (naf, nbf) when `prefetch`, and
@@ -65,8 +74,9 @@ __device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], cons
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      sp_mfma(acc[i][j], bf[j], af[i]);
       const int n = i * FN + j;
+      if (n == TOTAL - 1) sp_mfma_last(acc[i][j], bf[j], af[i]);
+      else sp_mfma(acc[i][j], bf[j], af[i]);
       if (n < NRD) {
         // unconditional: behind the last tile this reads stale (never used) LDS, no branch needed
         if (n < FN) nbf[n] = *(const f16x8*)(next_b + n * 16 * ROW_BYTES);
@@ -78,9 +88,9 @@ __device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], cons
           const int piece = wave + p * CFG::NW;
           lds_void_t* dst = (lds_void_t*)(lds_stage + piece * 1024);
           if (piece < CFG::NI_A)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
           else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
         }
       }
     }
@@ -171,11 +181,6 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
                      st, wave, kbyte, issue);
     if (t + 2 < nk) kbyte += ROW_BYTES;
   }
-  // MFMA results -> VALU/store readers: wait states hipcc cannot see behind the asm MFMAs
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
   store_tile<16, FM, FN, CFG::TM, CFG::TN, SPLITK>(g, tc, wave_m, wave_n, lane, acc);
 #endif  // __HIP_DEVICE_COMPILE__
 }

@@ -77,6 +77,9 @@ int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* gro
  * pruning and for reports: estimated microseconds of (config_id, splits) on (M,N,K). */
 double hgemm_mi355x_model_us(int config_id, int splits, int M, int N, int K);
 
+/* Raster group height the planner uses for (config, M, N) when no tuned value exists. */
+int hgemm_mi355x_default_group(int config_id, int M, int N);
+
 /* Geometry table introspection (ids are stable positions in csrc/hgemm_configs.def). */
 int hgemm_mi355x_num_configs(void);
 const char* hgemm_mi355x_config_name(int config_id);

@@ -300,3 +300,24 @@ def pp_schedule_hazards(NU: int, P: int = 4):
                     if not issue_iv[(g, v)] >= Mi(g2, v - 4) + 1:
                         bad.append(("refill too early", g, v, g2, issue_iv[(g, v)], Mi(g2, v - 4)))
     return bad
+
+
+def wide_epilogue_columns(fn: int):
+    """Replay of store_tile's wide path: for each fragment pair (j, j+1) and lane, the 8 consecutive
+    N offsets (inside the wave tile) the lane stores after v_permlane16_swap.  permlane16_swap(vdst, src):
+    vdst' rows = [v.r0, s.r0, v.r2, s.r2], src' rows = [v.r1, s.r1, v.r3, s.r3] (rows = 16-lane groups)."""
+    out = {}
+    for j in range(0, fn, 2):
+        # per lane, the n offsets held before the swap: tile j -> a (4 values), tile j+1 -> b
+        a = {lane: [16 * j + (lane >> 4) * 4 + e for e in range(4)] for lane in range(64)}
+        b = {lane: [16 * (j + 1) + (lane >> 4) * 4 + e for e in range(4)] for lane in range(64)}
+        for lane in range(64):
+            q, l15 = lane >> 4, lane & 15
+            # a' (vdst'): even rows keep a, odd rows receive b's row q-1;  b' (src'): even rows receive a's row q+1
+            a_new = a[lane] if q % 2 == 0 else b[(q - 1) * 16 + l15]
+            b_new = b[lane] if q % 2 == 1 else a[(q + 1) * 16 + l15]
+            cols = a_new + b_new                       # store order [a0', a1', b0', b1']
+            n_base = 16 * (j + (q & 1)) + 8 * (q >> 1)
+            assert cols == list(range(n_base, n_base + 8)), (lane, cols, n_base)
+            out[(j, lane)] = cols
+    return out

@@ -106,3 +106,11 @@ def test_pingpong_tile_matches_numpy_and_is_bank_conflict_free(geo):
 @pytest.mark.parametrize("NU", [2, 3, 4, 5, 6, 8, 9, 32, 128])
 def test_pingpong_schedule_has_no_lds_hazard(NU):
     assert klm.pp_schedule_hazards(NU) == []
+
+
+@pytest.mark.parametrize("fn", [2, 4, 8])
+def test_wide_epilogue_permlane_mapping(fn):
+    cols = klm.wide_epilogue_columns(fn)
+    for l15 in range(16):  # every C row of the fragment: each of the fn*16 columns stored exactly once
+        seen = sorted(c for (j, lane), cs in cols.items() if lane & 15 == l15 for c in cs)
+        assert seen == list(range(fn * 16))
