@@ -1,0 +1,45 @@
+"""Summarise a bin/hgemm_tune --baselines run: geomean speedups, per-size buckets, worst shapes."""
+import collections
+import json
+import math
+import sys
+
+
+def gm(x):
+    x = list(x)
+    return math.exp(sum(map(math.log, x)) / len(x)) if x else float("nan")
+
+
+def main(path, show=12):
+    recs = [json.loads(l) for l in open(path) if l.strip()]
+    rows = []
+    for r in recs:
+        m, n, k = map(int, r["mnk"].split("_"))
+        fl = 2.0 * m * n * k
+        ours = r["best"]["us"]
+        lt = min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"])
+        rb = min(r["rocblas_tn_us"], r["rocblas_nn_us"])
+        rows.append({"mnk": r["mnk"], "flops": fl, "ours": ours, "lt": lt, "rb": rb, "sp_lt": lt / ours, "sp_rb": rb / ours,
+                     "sp_lt_tn": r["hipblaslt_heur_tn_us"] / ours, "sp_lt_nn": r["hipblaslt_heur_nn_us"] / ours, "best": r["best"]})
+    out = {"shapes": len(rows),
+           "geomean_speedup_vs_hipblaslt_heuristic_max": gm(x["sp_lt"] for x in rows),
+           "geomean_speedup_vs_hipblaslt_heuristic_tn": gm(x["sp_lt_tn"] for x in rows),
+           "geomean_speedup_vs_hipblaslt_heuristic_nn": gm(x["sp_lt_nn"] for x in rows),
+           "geomean_speedup_vs_rocblas_max": gm(x["sp_rb"] for x in rows),
+           "mean_speedup_vs_hipblaslt_heuristic_max": sum(x["sp_lt"] for x in rows) / len(rows),
+           "fraction_faster_than_hipblaslt_heuristic_max": sum(x["sp_lt"] > 1 for x in rows) / len(rows),
+           "aggregate_tflops_ours": sum(x["flops"] for x in rows) / sum(x["ours"] for x in rows) * 1e-6,
+           "aggregate_tflops_hipblaslt_max": sum(x["flops"] for x in rows) / sum(x["lt"] for x in rows) * 1e-6}
+    buckets = collections.defaultdict(list)
+    for x in rows:
+        buckets[int(math.log10(x["flops"]))].append(x["sp_lt"])
+    out["by_log10_flops"] = {b: {"n": len(v), "geomean": round(gm(v), 3), "min": round(min(v), 2), "max": round(max(v), 2)} for b, v in sorted(buckets.items())}
+    print(json.dumps(out, indent=1))
+    for x in sorted(rows, key=lambda x: x["sp_lt"])[:show]:
+        print("  worst %-20s ours %9.1f us (%s s=%d g=%d)  hipblaslt %9.1f us  speedup %.2f" % (
+            x["mnk"], x["ours"], x["best"]["config"], x["best"]["splits"], x["best"]["group_m"], x["lt"], x["sp_lt"]))
+    return out
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12)
