@@ -8,19 +8,28 @@
 //     (256 accumulator registers + two fragment sets), wave tile 128 x 128:
 //     LDS fragment traffic per K-step drops from 192 KiB to 128 KiB and a barrier joins 4 waves.
 //   * same LDS image and LDS-DMA staging as hgemm_tn_kernel (full 128-B lines, 2 stages);
-//   * register-level software pipelining ACROSS the barrier: the fragments of the next K=32
-//     slice are read while the current slice's 64 MFMAs run, so the wave that owns the matrix
-//     pipe never waits on LDS right after a barrier.  Per K-step (tile t, stage s = t & 1):
+//   * register-level software pipelining ACROSS the barriers: the fragments of the next K=32
+//     slice are read behind the first MFMAs of the current slice, so the wave that owns the matrix
+//     pipe never waits on LDS right after a barrier.
+//   * an operand-split LDS-DMA stream with ~one K-step of flight time for EVERY piece.  Measured
+//     on MI355X (profiles/): hipBLASLt's kernel of the same geometry has the same L2 hit rate but
+//     parks its waves 10 % of the time against 36-43 % here; disassembling its main loop shows why:
+//     it needs the A half of the next tile mid-loop and the B half later, and issues them in that
+//     order a full iteration earlier.  Same idea here.  K-step t (stage s = t & 1) has 2*T MFMA
+//     slots (T = FM*FN; interval A = slice 0, interval B = slice 1):
 //
-//       interval A:  ds_read slice 1 of tile t  -> set B   ||  64 MFMAs on set A (slice 0)
-//       lgkmcnt(0), vmcnt(0), s_barrier                        (tile t+1 landed; stage s is free)
-//       interval B:  LDS-DMA tile t+2 -> stage s (interleaved) ||
-//                    ds_read slice 0 of tile t+1 -> set A    ||  64 MFMAs on set B (slice 1)
+//       A[0, FM+FN)      ds_read slice 1 of tile t (A fragments, then B fragments) -> set B
+//       X1  A[FM+FN+4]   lgkmcnt(0) + barrier: the A region of stage s is free
+//       A(X1, T)         DMA: the A pieces of tile t+2 -> stage s
+//       Y1  end of A     vmcnt + barrier: the A pieces of tile t+1 have landed (their B pieces and the
+//                        A pieces of t+2 may still fly); also frees the B region of stage s
+//       B[0, FM)         ds_read slice 0 A fragments of tile t+1 -> set A
+//       B[2, T)          DMA: the B pieces of tile t+2 -> stage s
+//       Y2  B[T/2]       vmcnt + barrier: the B pieces of tile t+1 have landed
+//       B[T/2, T/2+FN)   ds_read slice 0 B fragments of tile t+1 -> set A
 //
-//     One barrier per K-step.  At the barrier every wave has retired all of its reads of stage s
-//     (WAR for the refill issued right after it) and has waited for its own pieces of tile t+1
-//     (RAW for the reads issued right after it); only tile t+1 is ever outstanding at the wait,
-//     so vmcnt(0) is exact, not a drain of younger loads.
+//     A pieces fly from A(X1,T) of K-step t to Y1 of K-step t+1, B pieces from interval B to Y2 of
+//     the next K-step: >= ~100 MFMA slots (~1600 cycles) each, against ~48 with a single sync point.
 #pragma once
 
 #include "hgemm_kernel.hpp"
@@ -41,9 +50,12 @@ struct CfgSP : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
 // fragments/accumulators between the VGPR and AGPR halves at 256 accumulators per lane
 // (v_accvgpr_read/write around every MFMA).  asm volatile also pins the issue ORDER, so the
 // ds_read / LDS-DMA instructions written between two MFMAs below stay between them.
-// `s_nop 1`: wait states hipcc does not insert inside an asm string (VALU-written operand -> MFMA).
+// No leading s_nop: with one wave per SIMD the 16-cycle MFMA issue interval leaves ~3 issue slots,
+// and a nop per MFMA next to the interleaved ds_read / DMA instructions overflows them.  The
+// fragment operands are only ever written by ds_read (waited for by lgkmcnt), never by a VALU
+// instruction; tests/test_build_audit.py asserts that the loop contains no VALU write (v_mov etc.).
 __device__ __forceinline__ void sp_mfma(f32x4& acc, const f16x8& a, const f16x8& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // Last MFMA of an interval.  hipcc cannot see the MFMAs inside the asm statements, so it pads
 // nothing between them and its own readers of their results -- and after the K loop it does place
@@ -52,48 +64,99 @@ __device__ __forceinline__ void sp_mfma(f32x4& acc, const f16x8& a, const f16x8&
 // reader wait states (8-pass XDL) therefore travel inside the statement itself: 16 states behind the
 // last MFMA also cover its predecessors, which are at least one MFMA issue older each.
 __device__ __forceinline__ void sp_mfma_last(f32x4& acc, const f16x8& a, const f16x8& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
 }
 
-// One interval: FM*FN MFMAs on the current fragment set (af, bf) with, in the issue slots between
-// them, (a) the FM+FN fragment reads of the NEXT K=32 slice into (naf, nbf) when `prefetch`, and
-// (b) this wave's NJ LDS-DMA pieces of the tile after next when `issue`.
+// Slot plan of one K-step (see the header comment).
 template <class CFG>
+struct SpPlan {
+  static constexpr int FM = CFG::FM, FN = CFG::FN, T = FM * FN;
+  static constexpr int NJA = CFG::NI_A / CFG::NW;            // A pieces per wave per tile
+  static constexpr int NJB = CFG::NJ - NJA;                  // B pieces per wave per tile
+  static constexpr int RS = 2;                               // one fragment read every RS MFMA slots
+  static constexpr int X1 = RS * FM + 4;                     // slot of interval A that carries the X1 sync
+  static constexpr int Y2 = T / 2;                           // slot of interval B that carries the Y2 sync
+  // A piece a (0..NJA-1) fires behind slot X1 + a*(T-1-X1)/NJA of interval A
+  static constexpr int a_slot(int a) { return X1 + (a * (T - 1 - X1)) / NJA; }
+  // B piece b (0..NJB-1) fires behind slot 2 + b*(T-3)/NJB of interval B
+  static constexpr int b_slot(int b) { return 2 + (b * (T - 3)) / NJB; }
+  static constexpr int a_at(int slot) { for (int a = 0; a < NJA; ++a) if (a_slot(a) == slot) return a; return -1; }
+  static constexpr int b_at(int slot) { for (int b = 0; b < NJB; ++b) if (b_slot(b) == slot) return b; return -1; }
+  static constexpr int b_before_y2() { int c = 0; for (int b = 0; b < NJB; ++b) c += b_slot(b) < Y2; return c; }
+  static constexpr int NB1 = b_before_y2();                  // B pieces of tile t+2 issued ahead of Y2
+  static_assert(CFG::NI_A % CFG::NW == 0 && CFG::NJ > NJA, "every wave owns whole A and B pieces");
+  static_assert(X1 < T - NJA && RS * FM <= Y2 && Y2 + RS * FN <= T && RS * (FM + FN) <= T, "slot plan does not fit the interval");
+  static_assert(a_slot(NJA - 1) < T && b_slot(NJB - 1) < T && a_slot(0) != a_slot(1 % NJA) , "distinct slots");
+};
+
+template <class CFG>
+__device__ __forceinline__ void sp_issue_piece(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[CFG::NJ], char* lds_stage,
+                                               int wave, int p, uint32_t kbyte) {
+  lds_void_t* dst = (lds_void_t*)(lds_stage + (wave + p * CFG::NW) * 1024);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
+}
+
+__device__ __forceinline__ void sp_sync() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One interval (PHASE 0 = A, 1 = B): T MFMAs on (af, bf) with the reads / DMA pieces / sync points
+// of the slot plan between them.  `has1` / `has2` are wave-uniform (tile t+1 / t+2 exist).  ONE body
+// for all cases: two instantiations behind an if/else make hipcc shuffle all 256 accumulators.
+template <class CFG, int PHASE>
 __device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], const f16x8 (&af)[CFG::FM],
                                             const f16x8 (&bf)[CFG::FN], f16x8 (&naf)[CFG::FM],
                                             f16x8 (&nbf)[CFG::FN], const char* next_a, const char* next_b,
                                             __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
-                                            const uint32_t (&voff)[CFG::NJ], char* lds_stage, int wave,
-                                            uint32_t kbyte, bool issue) {
-  constexpr int FM = CFG::FM, FN = CFG::FN, TOTAL = FM * FN, NJ = CFG::NJ;
-  constexpr int NRD = FM + FN;            // fragment reads of the next slice
-  constexpr int DMA0 = NRD;               // DMA pieces go behind the reads
-  static_assert(TOTAL >= NRD + NJ, "one issue slot per prefetch read and per DMA piece");
-  constexpr int DSTEP = (TOTAL - DMA0) / NJ;
+                                            const uint32_t (&voff)[CFG::NJ], int wave, char* stage2, uint32_t kbyte2,
+                                            bool has1, bool has2) {
+  using P = SpPlan<CFG>;
+  constexpr int FM = CFG::FM, FN = CFG::FN, T = FM * FN;
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = i * FN + j;
-      if (n == TOTAL - 1) sp_mfma_last(acc[i][j], bf[j], af[i]);
+      if (PHASE == 0 && n == P::X1) {                       // X1: the slice-1 A-fragment reads of tile t are retired
+        // LDS returns in order: only the B-fragment reads issued since may still be outstanding
+        constexpr int YOUNGER = (P::X1 + P::RS - 1) / P::RS - FM;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(YOUNGER > 0 ? YOUNGER : 0) : "memory");
+        sp_sync();
+      }
+      if (PHASE == 1 && n == P::Y2) {                       // Y2: B pieces of tile t+1 have landed
+        wait_vmcnt<P::NJA + P::NB1>();
+        sp_sync();
+      }
+      if (n == T - 1) sp_mfma_last(acc[i][j], bf[j], af[i]);
       else sp_mfma(acc[i][j], bf[j], af[i]);
-      if (n < NRD) {
-        // unconditional: behind the last tile this reads stale (never used) LDS, no branch needed
-        if (n < FN) nbf[n] = *(const f16x8*)(next_b + n * 16 * ROW_BYTES);
-        else        naf[n - FN] = *(const f16x8*)(next_a + (n - FN) * 16 * ROW_BYTES);
-      } else if ((n - DMA0) % DSTEP == 0 && (n - DMA0) / DSTEP < NJ) {
-        if (issue) {  // wave-uniform; ONE body for both cases (two instantiations behind an if/else
-                      // make hipcc shuffle all 256 accumulators between the branches)
-          const int p = (n - DMA0) / DSTEP;
-          const int piece = wave + p * CFG::NW;
-          lds_void_t* dst = (lds_void_t*)(lds_stage + piece * 1024);
-          if (piece < CFG::NI_A)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
-          else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, voff[p], kbyte, 0, HGEMM_DMA_AUX);
+      // fragment reads of the next slice, one every RS slots so the four waves (which leave every
+      // sync point together) do not saturate the LDS pipe (unconditional: behind the last tile they
+      // read stale LDS, which is never used)
+      constexpr int RS = P::RS;
+      if (n % RS == 0) {
+        const int r = n / RS;
+        if (PHASE == 0) {
+          if (r < FM) naf[r] = *(const f16x8*)(next_a + r * 16 * ROW_BYTES);
+          else if (r < FM + FN) nbf[r - FM] = *(const f16x8*)(next_b + (r - FM) * 16 * ROW_BYTES);
+        } else {
+          if (r < FM) naf[r] = *(const f16x8*)(next_a + r * 16 * ROW_BYTES);
+          else if (n >= P::Y2 && (n - P::Y2) / RS < FN) nbf[(n - P::Y2) / RS] = *(const f16x8*)(next_b + ((n - P::Y2) / RS) * 16 * ROW_BYTES);
         }
       }
+      // LDS-DMA pieces of tile t+2 into the stage tile t is vacating.  Branch-free: behind the last
+      // tile kbyte2 is clamped to the last valid K offset, so the redundant pieces read valid memory
+      // and land in a stage nobody reads again (one wave per SIMD: a branch per piece costs MFMA issue)
+      if (PHASE == 0) {
+        const int a = P::a_at(n);
+        if (a >= 0) sp_issue_piece<CFG>(rsA, voff, stage2, wave, a, kbyte2);
+      } else {
+        const int b = P::b_at(n);
+        if (b >= 0) sp_issue_piece<CFG>(rsB, voff, stage2, wave, P::NJA + b, kbyte2);
+      }
     }
+  (void)has1; (void)has2;
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
@@ -144,43 +207,39 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: tiles 0 and 1 in flight; tile 0 visible; slice 0 of tile 0 in set A -------------
-  uint32_t kbyte = (uint32_t)tc.k_begin * 2u;
-  stage_tile<CFG>(rsA, rsB, voff, smem, wave, kbyte);
-  kbyte += ROW_BYTES;
-  if (nk > 1) {
-    stage_tile<CFG>(rsA, rsB, voff, smem + CFG::STAGE_BYTES, wave, kbyte);
-    kbyte += ROW_BYTES;
-    wait_vmcnt<NJ>();
-  } else {
-    wait_vmcnt<0>();
-  }
+  // ---- prologue: tiles 0 and 1 in flight (A pieces first, then B pieces); tile 0 visible --------
+  using P = SpPlan<CFG>;
+  const uint32_t kb0 = (uint32_t)tc.k_begin * 2u;
+  stage_tile<CFG>(rsA, rsB, voff, smem, wave, kb0);
+  // tile 1 (or, for a single-tile K range, tile 0 again: same branch-free clamping as in the loop)
+  stage_tile<CFG>(rsA, rsB, voff, smem + CFG::STAGE_BYTES, wave, kb0 + (nk > 1 ? ROW_BYTES : 0));
+  wait_vmcnt<NJ>();
   __builtin_amdgcn_s_barrier();
 
   f16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) bfA[j] = *(const f16x8*)(smem + b_base_off + off0 + j * 16 * ROW_BYTES);
-#pragma unroll
   for (int i = 0; i < FM; ++i) afA[i] = *(const f16x8*)(smem + a_base_off + off0 + i * 16 * ROW_BYTES);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bfA[j] = *(const f16x8*)(smem + b_base_off + off0 + j * 16 * ROW_BYTES);
 
   for (int t = 0; t < nk; ++t) {
-    char* st  = smem + (t & 1) * CFG::STAGE_BYTES;        // stage of tile t
+    char* st  = smem + (t & 1) * CFG::STAGE_BYTES;        // stage of tile t (and of tile t+2)
     char* nst = smem + ((t + 1) & 1) * CFG::STAGE_BYTES;  // stage of tile t+1
-    // ---- interval A: MFMAs on slice 0 (set A); slice 1 of tile t streams into set B ----------------
-    sp_interval<CFG>(acc, afA, bfA, afB, bfB, st + a_base_off + off1, st + b_base_off + off1, rsA, rsB, voff,
-                     st, wave, kbyte, false);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage (t&1) are retired
-    wait_vmcnt<0>();                                      // my pieces of tile t+1 have landed
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- interval B: MFMAs on slice 1 (set B); slice 0 of tile t+1 streams into set A; the refill
-    //      of stage (t&1) with tile t+2 is issued behind the reads ------------------------------------
-    const bool issue = (t + 2 < nk) && !(g.debug & 1);
-    sp_interval<CFG>(acc, afB, bfB, afA, bfA, nst + a_base_off + off0, nst + b_base_off + off0, rsA, rsB, voff,
-                     st, wave, kbyte, issue);
-    if (t + 2 < nk) kbyte += ROW_BYTES;
+    // K byte offset of tile t+2, clamped to the last tile (see sp_interval: branch-free DMA)
+    const uint32_t kb2 = kb0 + (uint32_t)min(t + 2, nk - 1) * ROW_BYTES;
+    const bool has1 = (t + 1 < nk), has2 = (t + 2 < nk);
+    // ---- interval A: MFMAs on slice 0 (set A); slice 1 of tile t streams into set B -----------------
+    sp_interval<CFG, 0>(acc, afA, bfA, afB, bfB, st + a_base_off + off1, st + b_base_off + off1, rsA, rsB, voff, wave,
+                        st, kb2, has1, has2);
+    // Y1: my A pieces of tile t+1 have landed; its B pieces and the A pieces of tile t+2 may fly on
+    wait_vmcnt<P::NJB + P::NJA>();
+    sp_sync();
+    // ---- interval B: MFMAs on slice 1 (set B); slice 0 of tile t+1 streams into set A ---------------
+    sp_interval<CFG, 1>(acc, afB, bfB, afA, bfA, nst + a_base_off + off0, nst + b_base_off + off0, rsA, rsB, voff, wave,
+                        st, kb2, has1, has2);
   }
+
+  wait_vmcnt<0>();  // the redundant tail pieces must not outlive the workgroup's LDS allocation
   store_tile<16, FM, FN, CFG::TM, CFG::TN, SPLITK>(g, tc, wave_m, wave_n, lane, acc);
 #endif  // __HIP_DEVICE_COMPILE__
 }
