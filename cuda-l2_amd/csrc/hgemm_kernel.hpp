@@ -46,6 +46,17 @@ constexpr int NUM_XCD   = 8;
 
 // cache-policy bits of the LDS-DMA loads (buffer_load ... lds aux operand: 1 = sc0, 2 = nt, 16 = sc1).
 // 0 = default policy; other values are build-time experiments (build.py HGEMM_EXTRA_HIPFLAGS).
+// C stores: each C element is written once and never re-read by the kernel.  HGEMM_NT_STORE=1 marks the
+// fp16 output stores non-temporal (streaming), so they do not displace the A/B panels from L2.
+#ifndef HGEMM_NT_STORE
+#define HGEMM_NT_STORE 0
+#endif
+#if HGEMM_NT_STORE
+#define HGEMM_STORE_C(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define HGEMM_STORE_C(ptr, val) (*(ptr) = (val))
+#endif
+
 #ifndef HGEMM_DMA_AUX
 #define HGEMM_DMA_AUX 0
 #endif
@@ -63,7 +74,8 @@ struct GemmArgs {
   int splits;
   int tiles_m, tiles_n;
   int group_m;     // rasterisation group height in tiles
-  int debug;       // bit 0: skip steady-state LDS-DMA (ablation only; results are garbage)
+  int debug;       // ablation only (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
+                   // epilogue stores, bit 2 cut every tile's K loop to two steps
 };
 
 // Compile-time geometry of one kernel instantiation.
@@ -123,6 +135,7 @@ __device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN
   tc.n0 = (tin / gm) * BN;
   tc.k_begin = split * g.k_chunk;
   tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin) / BK;
+  if (g.debug & 4) tc.nk = min(tc.nk, 2);
   return tc;
 }
 
@@ -132,15 +145,21 @@ __device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN
 //   MI=32: m = (lane & 31),  n = 8 * q + 4 * (lane >> 5) + e,  reg = 4*q+e (q = 0..3)
 // The host only takes the MFMA path when N % 4 == 0, ldc % 4 == 0 and C is 8-byte aligned, so a
 // quad is either fully inside or fully outside the matrix.
-template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, class ACC>
+// WIDE: -1 = pick the path at run time; 0 / 1 = only the narrow / wide path is compiled (the host chose).
+// Families whose accumulators fill the register file need the single-path forms: with both paths
+// present the compiler hoists their common fp32->fp16 conversions above the branch, which makes all
+// FM*FN*4 values live at once.
+template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, int WIDE = -1, class ACC>
 __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& tc, int wave_m,
                                            int wave_n, int lane, ACC (&acc)[FM][FN]) {
   // Wide path (fp16 output, 16x16 MFMA tiles, FN even): v_permlane16_swap exchanges the odd 16-lane
   // rows of tile j with the even rows of tile j+1, after which every lane owns 8 consecutive N
   // (16 bytes) of its C row: half the store instructions, 64 contiguous bytes per row per store.
   //   row q = lane >> 4 ends up with n = 16*(j + (q & 1)) + 8*(q >> 1) + 0..7
-  if constexpr (!SPLITK && MI == 16 && (FN % 2 == 0)) {
-    const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  if (g.debug & 2) return;
+  if constexpr (!SPLITK && MI == 16 && (FN % 2 == 0) && WIDE != 0) {
+    const bool wide = (WIDE == 1) ||
+                      (((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0));
     if (wide) {
       const int q = lane >> 4;
 #pragma unroll
@@ -158,7 +177,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& t
           if (m < g.M && n < g.N) {
             using u4 = __attribute__((ext_vector_type(4))) unsigned;
             const u4 o = {r0[0], r1[0], r0[1], r1[1]};
-            *(u4*)(g.C + (size_t)m * g.ldc + n) = o;
+            HGEMM_STORE_C((u4*)(g.C + (size_t)m * g.ldc + n), o);
           }
         }
       }
@@ -190,7 +209,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& t
             f16* dst = g.C + (size_t)m * g.ldc + n;
             f16x4 o = {(f16)acc[i][j][q * 4 + 0], (f16)acc[i][j][q * 4 + 1],
                        (f16)acc[i][j][q * 4 + 2], (f16)acc[i][j][q * 4 + 3]};
-            *(f16x4*)dst = o;
+            HGEMM_STORE_C((f16x4*)dst, o);
           }
         }
       }

@@ -160,7 +160,9 @@ __device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], cons
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <class CFG, bool SPLITK>
+// EPI: 0 = narrow fp16 epilogue, 1 = wide fp16 epilogue (host checked N % 8, ldc % 8, 16-B aligned C),
+//      2 = fp32 split-K partials
+template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NW = CFG::NW, NJ = CFG::NJ;
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   }
 
   wait_vmcnt<0>();  // the redundant tail pieces must not outlive the workgroup's LDS allocation
-  store_tile<16, FM, FN, CFG::TM, CFG::TN, SPLITK>(g, tc, wave_m, wave_n, lane, acc);
+  store_tile<16, FM, FN, CFG::TM, CFG::TN, EPI == 2, EPI == 2 ? -1 : EPI>(g, tc, wave_m, wave_n, lane, acc);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -33,10 +33,13 @@ void launch_pp(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
 
 template <class CFG>
 void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
+  const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
   if (splitk)
-    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, true>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, 2>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+  else if (wide)
+    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, 1>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
   else
-    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, false>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
+    hipLaunchKernelGGL((hgemm_tn_sp_kernel<CFG, 0>), dim3(grid), dim3(CFG::THREADS), 0, stream, g);
 }
 
 struct KernelEntry {

@@ -394,7 +394,9 @@ int main(int argc, char** argv) {
   }
   if (mode == "bench") {
     if (shapes.empty()) { fprintf(stderr, "bench needs --shape\n"); return 2; }
-    return cmd_bench(shapes[0], cfg_name, splits, group, reps, use_lib);
+    int rc = 0;
+    for (const Shape& sh : shapes) rc |= cmd_bench(sh, cfg_name, splits, group, reps, use_lib);
+    return rc;
   }
   fprintf(stderr, "unknown mode %s\n", mode.c_str());
   return 2;

@@ -1,6 +1,6 @@
 // M=1024 N=1024 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t256x128_w4x2_m32_s3, split-K 8, raster group 2  [tuned on MI355X: 40.8 us, 632 TFLOP/s]
+// plan: geometry s128x256_w2x2, split-K 8, raster group 1  [tuned on MI355X: 38.4 us, 671 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 1024, 12288, "t256x128_w4x2_m32_s3", 8, 2)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 1024, 12288, "s128x256_w2x2", 8, 1)

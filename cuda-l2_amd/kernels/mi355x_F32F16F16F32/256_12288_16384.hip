@@ -1,6 +1,6 @@
 // M=256 N=12288 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t256x256_w2x4_m16_s2, split-K 4, raster group 8  [tuned on MI355X: 141.0 us, 731 TFLOP/s]
+// plan: geometry s256x256_w2x2, split-K 4, raster group 1  [tuned on MI355X: 145.0 us, 711 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 12288, 16384, "t256x256_w2x4_m16_s2", 4, 8)
+HGEMM_MI355X_SHAPE_ENTRY(256, 12288, 16384, "s256x256_w2x2", 4, 1)

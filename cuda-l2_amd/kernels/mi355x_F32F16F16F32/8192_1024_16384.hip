@@ -1,6 +1,6 @@
 // M=8192 N=1024 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t256x256_w2x4_m16_s2, split-K 2, raster group 4  [tuned on MI355X: 242.9 us, 1131 TFLOP/s]
+// plan: geometry s256x256_w2x2, split-K 2, raster group 2  [tuned on MI355X: 222.8 us, 1234 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 1024, 16384, "t256x256_w2x4_m16_s2", 2, 4)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 1024, 16384, "s256x256_w2x2", 2, 2)
