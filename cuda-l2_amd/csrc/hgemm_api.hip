@@ -265,7 +265,9 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, c
       int st = ensure_workspace(hgemm_mi355x_workspace_bytes(M, N, splits), &g.partial);
       if (st != HGEMM_OK) return st;
     }
-    e.launch(g, (int)grid, s, splits > 1);
+    // persistent families walk their work items themselves: one resident wave of workgroups
+    const long launch_grid = (e.persistent_wgs > 0) ? std::min<long>(grid, e.persistent_wgs) : grid;
+    e.launch(g, (int)launch_grid, s, splits > 1);
     if (splits > 1) launch_splitk_reduce(g.partial, g.C, M, N, ldc, splits, s);
   }
   hipError_t err = hipGetLastError();

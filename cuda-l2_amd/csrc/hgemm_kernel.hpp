@@ -75,7 +75,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int group_m;     // rasterisation group height in tiles
   int debug;       // ablation only (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
-                   // epilogue stores, bit 2 cut every tile's K loop to two steps
+                   // epilogue stores, bit 2 cut every tile's K loop to two steps, bit 3 every tile stores to tile (0,0)
 };
 
 // Compile-time geometry of one kernel instantiation.
@@ -113,14 +113,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // compact patch of the tile grid, so the A/B panels a patch shares are hit in that XCD's L2.
 struct TileCoord { int split, m0, n0, k_begin, nk; };
 
-__device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN) {
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
-    const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+// logical work-item id (after the XCD remap) -> (split, tile origin, K range), grouped raster
+__device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int BM, int BN) {
   const int tiles = g.tiles_m * g.tiles_n;
   const int split = bid / tiles;
   const int t_id  = bid - split * tiles;
@@ -139,6 +133,37 @@ __device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN
   return tc;
 }
 
+__device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN) {
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
+    const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  return map_logical(g, bid, BM, BN);
+}
+
+// Persistent grids (fewer workgroups than work items): the workgroups that run on XCD x
+// (blockIdx % 8 == x) share the contiguous logical range XCD x would also get from map_block, and
+// walk it round by round -- the r-th item of workgroup j of that XCD is base_x + r * nwg_x + j -- so
+// the items an XCD processes concurrently stay a compact patch of the tile grid.
+struct ItemWalk { int base, stride, first, count; };   // item r -> logical id base + first + r*stride
+
+__device__ __forceinline__ ItemWalk persistent_walk(int total_items) {
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid % NUM_XCD, j = bid / NUM_XCD;
+  const int nwg_x = G / NUM_XCD + (xcd < G % NUM_XCD ? 1 : 0);
+  const int q = total_items / NUM_XCD, r = total_items % NUM_XCD;
+  const int items_x = q + (xcd < r ? 1 : 0);
+  ItemWalk w;
+  w.base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  w.stride = nwg_x;
+  w.first = j;
+  w.count = (j < items_x) ? (items_x - j + nwg_x - 1) / nwg_x : 0;
+  return w;
+}
+
 // Epilogue shared by the kernel families (MI = 16 or 32 accumulator layout, operands swapped):
 // lane holds C[m][n .. n+3] (4 consecutive N) per accumulator quad.
 //   MI=16: m = (lane & 15),  n = (lane >> 4) * 4 + e                       (e = 0..3)
@@ -149,36 +174,33 @@ __device__ __forceinline__ TileCoord map_block(const GemmArgs& g, int BM, int BN
 // Families whose accumulators fill the register file need the single-path forms: with both paths
 // present the compiler hoists their common fp32->fp16 conversions above the branch, which makes all
 // FM*FN*4 values live at once.
-template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, int WIDE = -1, class ACC>
-__device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& tc, int wave_m,
-                                           int wave_n, int lane, ACC (&acc)[FM][FN]) {
+//
+// One fragment row (fixed i, all FN tiles) of the epilogue; store_tile below walks the rows.
+template <int MI, int FN, int TM, int TN, bool SPLITK, int WIDE = -1, class ACC>
+__device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoord& tc, int wave_m, int wave_n,
+                                               int lane, int i, ACC (&row)[FN]) {
   // Wide path (fp16 output, 16x16 MFMA tiles, FN even): v_permlane16_swap exchanges the odd 16-lane
   // rows of tile j with the even rows of tile j+1, after which every lane owns 8 consecutive N
   // (16 bytes) of its C row: half the store instructions, 64 contiguous bytes per row per store.
   //   row q = lane >> 4 ends up with n = 16*(j + (q & 1)) + 8*(q >> 1) + 0..7
-  if (g.debug & 2) return;
   if constexpr (!SPLITK && MI == 16 && (FN % 2 == 0) && WIDE != 0) {
     const bool wide = (WIDE == 1) ||
                       (((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0));
     if (wide) {
       const int q = lane >> 4;
+      const int m = ((g.debug & 8) ? 0 : tc.m0) + wave_m * TM + i * 16 + (lane & 15);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int m = tc.m0 + wave_m * TM + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < FN; j += 2) {
-          using h2 = __attribute__((ext_vector_type(2))) _Float16;
-          const h2 a01 = {(f16)acc[i][j][0], (f16)acc[i][j][1]}, a23 = {(f16)acc[i][j][2], (f16)acc[i][j][3]};
-          const h2 b01 = {(f16)acc[i][j + 1][0], (f16)acc[i][j + 1][1]}, b23 = {(f16)acc[i][j + 1][2], (f16)acc[i][j + 1][3]};
-          const auto r0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, b01), false, false);
-          const auto r1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a23), __builtin_bit_cast(unsigned, b23), false, false);
-          const int n = tc.n0 + wave_n * TN + 16 * (j + (q & 1)) + 8 * (q >> 1);
-          if (m < g.M && n < g.N) {
-            using u4 = __attribute__((ext_vector_type(4))) unsigned;
-            const u4 o = {r0[0], r1[0], r0[1], r1[1]};
-            HGEMM_STORE_C((u4*)(g.C + (size_t)m * g.ldc + n), o);
-          }
+      for (int j = 0; j < FN; j += 2) {
+        using h2 = __attribute__((ext_vector_type(2))) _Float16;
+        const h2 a01 = {(f16)row[j][0], (f16)row[j][1]}, a23 = {(f16)row[j][2], (f16)row[j][3]};
+        const h2 b01 = {(f16)row[j + 1][0], (f16)row[j + 1][1]}, b23 = {(f16)row[j + 1][2], (f16)row[j + 1][3]};
+        const auto r0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, b01), false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a23), __builtin_bit_cast(unsigned, b23), false, false);
+        const int n = ((g.debug & 8) ? 0 : tc.n0) + wave_n * TN + 16 * (j + (q & 1)) + 8 * (q >> 1);
+        if (m < g.M && n < g.N) {
+          using u4 = __attribute__((ext_vector_type(4))) unsigned;
+          const u4 o = {r0[0], r1[0], r0[1], r1[1]};
+          HGEMM_STORE_C((u4*)(g.C + (size_t)m * g.ldc + n), o);
         }
       }
       return;
@@ -187,33 +209,37 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& t
   const int lm = (MI == 16) ? (lane & 15) : (lane & 31);
   const int ln = (MI == 16) ? ((lane >> 4) * 4) : ((lane >> 5) * 4);
   constexpr int NQ = (MI == 16) ? 1 : 4;
+  const int m = tc.m0 + wave_m * TM + i * MI + lm;
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    // keep the accumulator -> VGPR traffic of one fragment row together: without the fence the
-    // scheduler hoists all FM*FN*4 accumulator reads ahead of the first store, and at 256
-    // accumulators per lane that pressure leaks into the main loop's register allocation
-    __builtin_amdgcn_sched_barrier(0);
-    const int m = tc.m0 + wave_m * TM + i * MI + lm;
+  for (int j = 0; j < FN; ++j) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int n = tc.n0 + wave_n * TN + j * MI + q * 8 + ln;
-        if (m < g.M && n < g.N) {
-          if constexpr (SPLITK) {
-            float* dst = g.partial + ((size_t)tc.split * g.M + m) * g.N + n;
-            f32x4 o = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2],
-                       acc[i][j][q * 4 + 3]};
-            *(f32x4*)dst = o;
-          } else {
-            f16* dst = g.C + (size_t)m * g.ldc + n;
-            f16x4 o = {(f16)acc[i][j][q * 4 + 0], (f16)acc[i][j][q * 4 + 1],
-                       (f16)acc[i][j][q * 4 + 2], (f16)acc[i][j][q * 4 + 3]};
-            HGEMM_STORE_C((f16x4*)dst, o);
-          }
+    for (int q = 0; q < NQ; ++q) {
+      const int n = tc.n0 + wave_n * TN + j * MI + q * 8 + ln;
+      if (m < g.M && n < g.N) {
+        if constexpr (SPLITK) {
+          float* dst = g.partial + ((size_t)tc.split * g.M + m) * g.N + n;
+          f32x4 o = {row[j][q * 4 + 0], row[j][q * 4 + 1], row[j][q * 4 + 2], row[j][q * 4 + 3]};
+          *(f32x4*)dst = o;
+        } else {
+          f16* dst = g.C + (size_t)m * g.ldc + n;
+          f16x4 o = {(f16)row[j][q * 4 + 0], (f16)row[j][q * 4 + 1], (f16)row[j][q * 4 + 2], (f16)row[j][q * 4 + 3]};
+          HGEMM_STORE_C((f16x4*)dst, o);
         }
       }
     }
+  }
+}
+
+template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, int WIDE = -1, class ACC>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& tc, int wave_m,
+                                           int wave_n, int lane, ACC (&acc)[FM][FN]) {
+  if (g.debug & 2) return;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    // keep the accumulator -> VGPR traffic of one fragment row together: without the fence the
+    // scheduler hoists all FM*FN*4 accumulator reads ahead of the first store
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile_row<MI, FN, TM, TN, SPLITK, WIDE>(g, tc, wave_m, wave_n, lane, i, acc[i]);
   }
 }
 

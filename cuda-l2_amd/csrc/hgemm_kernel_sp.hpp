@@ -30,6 +30,11 @@
 //
 //     A pieces fly from A(X1,T) of K-step t to Y1 of K-step t+1, B pieces from interval B to Y2 of
 //     the next K-step: >= ~100 MFMA slots (~1600 cycles) each, against ~48 with a single sync point.
+//   * persistent: at most one workgroup per CU is launched and walks its work items ((split, tile)
+//     pairs, XCD-local round-robin, see persistent_walk).  The LDS-DMA issue stream runs two K-steps
+//     ahead of the MFMAs ACROSS work items, so the first two K-steps of the next output tile are in
+//     flight while the current tile is converted and stored: no workgroup launch and no exposed
+//     prologue latency per tile (measured: +12..20 % on K <= 1024 with M, N >= 8192, +2 % on 8192^3).
 #pragma once
 
 #include "hgemm_kernel.hpp"
@@ -45,26 +50,39 @@ struct CfgSP : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Accumulators are pinned to the accumulation half of the register file ("a" constraint) and the
-// MFMA is issued from inline asm with dst tied to srcC.  hipcc's allocator otherwise migrates
-// fragments/accumulators between the VGPR and AGPR halves at 256 accumulators per lane
-// (v_accvgpr_read/write around every MFMA).  asm volatile also pins the issue ORDER, so the
-// ds_read / LDS-DMA instructions written between two MFMAs below stay between them.
-// No leading s_nop: with one wave per SIMD the 16-cycle MFMA issue interval leaves ~3 issue slots,
-// and a nop per MFMA next to the interleaved ds_read / DMA instructions overflows them.  The
-// fragment operands are only ever written by ds_read (waited for by lgkmcnt), never by a VALU
-// instruction; tests/test_build_audit.py asserts that the loop contains no VALU write (v_mov etc.).
-__device__ __forceinline__ void sp_mfma(f32x4& acc, const f16x8& a, const f16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+// The accumulators never exist as C++ values: tile (i, j) of the wave tile lives in a[4n .. 4n+3],
+// n = i*FN + j, named explicitly in every asm statement ("n" operands print as plain integers).
+// hipcc otherwise (a) migrates fragments/accumulators between the VGPR and AGPR halves at 256
+// accumulators per lane (v_accvgpr_read/write around every MFMA), and (b) copies ALL of them into
+// VGPRs in one sweep in front of the epilogue, which in a persistent kernel spills everything that is
+// live across the epilogue (next tile's fragments, DMA offsets).  sp_reserve_agprs() makes the kernel
+// descriptor allocate a0..a255; nothing else may touch AGPRs: the kernel keeps its VGPR count far
+// below 256 so the allocator never spills into them, and tests/test_build_audit.py checks that the
+// ISA has no v_accvgpr_* outside the asm statements below.
+// asm volatile also pins the issue ORDER, so the ds_read / LDS-DMA instructions written between two
+// MFMAs stay between them.  No s_nop: with one wave per SIMD the 16-cycle MFMA issue interval leaves
+// ~3 issue slots, and the fragment operands are only ever written by ds_read (waited for by
+// lgkmcnt), never by a VALU instruction.
+__device__ __forceinline__ void sp_reserve_agprs() {
+  asm volatile("" ::: "a0", "a63", "a127", "a128", "a191", "a255");
 }
-// Last MFMA of an interval.  hipcc cannot see the MFMAs inside the asm statements, so it pads
-// nothing between them and its own readers of their results -- and after the K loop it does place
-// accumulator copies (v_accvgpr_read/mov from live-range splitting) straight behind the final MFMA;
-// observed: element 0 of the last accumulator one K-slice stale.  The required MFMA-result ->
-// reader wait states (8-pass XDL) therefore travel inside the statement itself: 16 states behind the
-// last MFMA also cover its predecessors, which are at least one MFMA issue older each.
-__device__ __forceinline__ void sp_mfma_last(f32x4& acc, const f16x8& a, const f16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
+__device__ __forceinline__ void sp_mfma(int n, const f16x8& a, const f16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(n * 4), "n"(n * 4 + 3));
+}
+// MFMA results -> v_accvgpr_read need the XDL write-back wait states; the compiler cannot see the
+// dependency, so the epilogue opens with them explicitly (once per output tile).
+__device__ __forceinline__ void sp_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15"); }
+__device__ __forceinline__ f32x4 sp_read_acc(int n) {
+  f32x4 r;
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\t"
+               "v_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+               : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3])
+               : "n"(n * 4), "n"(n * 4 + 1), "n"(n * 4 + 2), "n"(n * 4 + 3));
+  return r;
+}
+__device__ __forceinline__ void sp_zero_acc(int n) {
+  asm volatile("v_accvgpr_write_b32 a[%0], 0\n\tv_accvgpr_write_b32 a[%1], 0\n\t"
+               "v_accvgpr_write_b32 a[%2], 0\n\tv_accvgpr_write_b32 a[%3], 0" ::"n"(n * 4), "n"(n * 4 + 1), "n"(n * 4 + 2), "n"(n * 4 + 3));
 }
 
 // Slot plan of one K-step (see the header comment).
@@ -103,15 +121,14 @@ __device__ __forceinline__ void sp_sync() {
 }
 
 // One interval (PHASE 0 = A, 1 = B): T MFMAs on (af, bf) with the reads / DMA pieces / sync points
-// of the slot plan between them.  `has1` / `has2` are wave-uniform (tile t+1 / t+2 exist).  ONE body
-// for all cases: two instantiations behind an if/else make hipcc shuffle all 256 accumulators.
+// of the slot plan between them.  ONE body for all cases: two instantiations behind an if/else make
+// hipcc shuffle all 256 accumulators.
 template <class CFG, int PHASE>
-__device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], const f16x8 (&af)[CFG::FM],
+__device__ __forceinline__ void sp_interval(const f16x8 (&af)[CFG::FM],
                                             const f16x8 (&bf)[CFG::FN], f16x8 (&naf)[CFG::FM],
                                             f16x8 (&nbf)[CFG::FN], const char* next_a, const char* next_b,
                                             __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
-                                            const uint32_t (&voff)[CFG::NJ], int wave, char* stage2, uint32_t kbyte2,
-                                            bool has1, bool has2) {
+                                            const uint32_t (&voff)[CFG::NJ], int wave, char* stage2, uint32_t kbyte2) {
   using P = SpPlan<CFG>;
   constexpr int FM = CFG::FM, FN = CFG::FN, T = FM * FN;
 #pragma unroll
@@ -129,8 +146,7 @@ __device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], cons
         wait_vmcnt<P::NJA + P::NB1>();
         sp_sync();
       }
-      if (n == T - 1) sp_mfma_last(acc[i][j], bf[j], af[i]);
-      else sp_mfma(acc[i][j], bf[j], af[i]);
+      sp_mfma(n, bf[j], af[i]);
       // fragment reads of the next slice, one every RS slots so the four waves (which leave every
       // sync point together) do not saturate the LDS pipe (unconditional: behind the last tile they
       // read stale LDS, which is never used)
@@ -156,16 +172,75 @@ __device__ __forceinline__ void sp_interval(f32x4 (&acc)[CFG::FM][CFG::FN], cons
         if (b >= 0) sp_issue_piece<CFG>(rsB, voff, stage2, wave, P::NJA + b, kbyte2);
       }
     }
-  (void)has1; (void)has2;
 }
 #endif  // __HIP_DEVICE_COMPILE__
+
+// Per-lane LDS-DMA source offsets and (wave-uniform) descriptors of one work item's tile.  The
+// descriptors must be PROVABLY uniform (SGPRs): hipcc otherwise wraps every LDS-DMA in a waterfall
+// loop (v_readfirstlane / s_and_saveexec / s_cbranch_execnz), which shreds the MFMA stream -- hence
+// plain locals (no struct passed by reference) and readfirstlane on the base pointers.
+#define SP_LOAD_ISSUE_ITEM(ITEM)                                                                              \
+  do {                                                                                                        \
+    const TileCoord itc = map_logical(g, walk.base + walk.first + (ITEM) * walk.stride, BM, BN);              \
+    const uintptr_t a_addr = reinterpret_cast<uintptr_t>(g.A + (size_t)itc.m0 * g.lda);                       \
+    const uintptr_t b_addr = reinterpret_cast<uintptr_t>(g.Bt + (size_t)itc.n0 * g.ldb);                      \
+    const uintptr_t a_uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a_addr >> 32)) << 32) | \
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_addr);                  \
+    const uintptr_t b_uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b_addr >> 32)) << 32) | \
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b_addr);                  \
+    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_uni, 0, 0xFFFFFFFFu, 0x00020000);                        \
+    rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_uni, 0, 0xFFFFFFFFu, 0x00020000);                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_) {                                                       \
+      const int i_ = wave + j_ * CFG::NW;                                                                     \
+      const bool isA_ = i_ < CFG::NI_A;                                                                       \
+      const int il_ = isA_ ? i_ : i_ - CFG::NI_A;                                                             \
+      const int r_ = il_ * 8 + (lane >> 3);                                                                   \
+      const int rmax_ = isA_ ? (g.M - 1 - itc.m0) : (g.N - 1 - itc.n0);                                       \
+      const int ld_ = isA_ ? g.lda : g.ldb;                                                                   \
+      const int chunk_ = (lane & 7) ^ (((il_ & 1) << 2) | (lane >> 4));                                       \
+      voff[j_] = ((uint32_t)min(r_, rmax_) * (uint32_t)ld_ + (uint32_t)chunk_ * 8u) * 2u;                     \
+    }                                                                                                         \
+    iss_kbyte = (uint32_t)__builtin_amdgcn_readfirstlane(itc.k_begin * 2);                                    \
+    iss_item = (ITEM); iss_kt = 0; iss_nk = __builtin_amdgcn_readfirstlane(itc.nk);                           \
+  } while (0)
+
+// Move the issue stream one K-step on; past the last step of the last item it stays put (the
+// branch-free DMA then re-reads that valid tile into a stage nobody consumes).
+#define SP_ISSUE_ADVANCE()                                   \
+  do {                                                       \
+    if (iss_kt + 1 < iss_nk) {                               \
+      ++iss_kt;                                              \
+      iss_kbyte += ROW_BYTES;                                \
+    } else if (iss_item + 1 < walk.count) {                  \
+      SP_LOAD_ISSUE_ITEM(iss_item + 1);                      \
+    }                                                        \
+  } while (0)
+
+// One K-step: intervals A and B on stage (step & 1); the DMA pieces belong to stream step + 2.
+#define SP_K_STEP()                                                                                            \
+  do {                                                                                                         \
+    char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                          \
+    char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                    \
+    /* interval A: MFMAs on slice 0 (set A); slice 1 of this step streams into set B */                        \
+    sp_interval<CFG, 0>(afA, bfA, afB, bfB, st + a_base_off + off1, st + b_base_off + off1, rsA, rsB,     \
+                        voff, wave, st, iss_kbyte);                                                            \
+    /* Y1: my A pieces of step+1 have landed; its B pieces and the A pieces of step+2 may fly on.  The       \
+       count is the number of YOUNGER LOADS only: loads retire in order among themselves, so it stays a      \
+       safe (merely conservative) bound while an epilogue's stores are still in the VM queue. */               \
+    wait_vmcnt<P::NJB + P::NJA>();                                                                             \
+    sp_sync();                                                                                                 \
+    /* interval B: MFMAs on slice 1 (set B); slice 0 of step+1 streams into set A */                           \
+    sp_interval<CFG, 1>(afB, bfB, afA, bfA, nst + a_base_off + off0, nst + b_base_off + off0, rsA, rsB,   \
+                        voff, wave, st, iss_kbyte);                                                            \
+    ++step;                                                                                                    \
+  } while (0)
 
 // EPI: 0 = narrow fp16 epilogue, 1 = wide fp16 epilogue (host checked N % 8, ldc % 8, 16-B aligned C),
 //      2 = fp32 split-K partials
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NW = CFG::NW, NJ = CFG::NJ;
+  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ;
 
   __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
 
@@ -175,26 +250,9 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   const int wave_m = wave / CFG::WN;
   const int wave_n = wave % CFG::WN;
 
-  const TileCoord tc = map_block(g, BM, BN);
-  const int nk = tc.nk;
-
-  const f16* a_base = g.A + (size_t)tc.m0 * g.lda;
-  const f16* b_base = g.Bt + (size_t)tc.n0 * g.ldb;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0xFFFFFFFFu, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0xFFFFFFFFu, 0x00020000);
-  uint32_t voff[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int i    = wave + j * NW;
-    const bool isA = i < CFG::NI_A;
-    const int il   = isA ? i : i - CFG::NI_A;
-    const int r    = il * 8 + (lane >> 3);
-    const int rmax = isA ? (g.M - 1 - tc.m0) : (g.N - 1 - tc.n0);
-    const int rc   = min(r, rmax);
-    const int ld   = isA ? g.lda : g.ldb;
-    const int chunk = (lane & 7) ^ (((il & 1) << 2) | (lane >> 4));
-    voff[j] = ((uint32_t)rc * (uint32_t)ld + (uint32_t)chunk * 8u) * 2u;
-  }
+  // persistent walk over this workgroup's work items ((split, tile) pairs)
+  const ItemWalk walk = persistent_walk(g.tiles_m * g.tiles_n * g.splits);
+  if (walk.count == 0) return;
 
   // fragment offsets of the two K=32 slices inside a stage (same image as hgemm_tn_kernel)
   const int l15 = lane & 15, lq = lane >> 4, sw = l15 >> 1;
@@ -203,18 +261,23 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   const int a_base_off = wave_m * CFG::TM * ROW_BYTES;
   const int b_base_off = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
 
-  f32x4 acc[FM][FN];
+  sp_reserve_agprs();
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
 
-  // ---- prologue: tiles 0 and 1 in flight (A pieces first, then B pieces); tile 0 visible --------
+  // ---- LDS-DMA issue stream: runs two K-steps ahead of the MFMAs and crosses work-item boundaries,
+  //      so the first tiles of the next output tile are in flight while the current one is stored ----
   using P = SpPlan<CFG>;
-  const uint32_t kb0 = (uint32_t)tc.k_begin * 2u;
-  stage_tile<CFG>(rsA, rsB, voff, smem, wave, kb0);
-  // tile 1 (or, for a single-tile K range, tile 0 again: same branch-free clamping as in the loop)
-  stage_tile<CFG>(rsA, rsB, voff, smem + CFG::STAGE_BYTES, wave, kb0 + (nk > 1 ? ROW_BYTES : 0));
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  uint32_t voff[NJ];
+  uint32_t iss_kbyte;
+  int iss_item, iss_kt, iss_nk;
+  SP_LOAD_ISSUE_ITEM(0);
+  // prologue: stream steps 0 and 1 in flight (A pieces first, then B pieces); step 0 visible
+  stage_tile<CFG>(rsA, rsB, voff, smem, wave, iss_kbyte);
+  SP_ISSUE_ADVANCE();
+  stage_tile<CFG>(rsA, rsB, voff, smem + CFG::STAGE_BYTES, wave, iss_kbyte);
+  SP_ISSUE_ADVANCE();
   wait_vmcnt<NJ>();
   __builtin_amdgcn_s_barrier();
 
@@ -224,26 +287,49 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
 #pragma unroll
   for (int j = 0; j < FN; ++j) bfA[j] = *(const f16x8*)(smem + b_base_off + off0 + j * 16 * ROW_BYTES);
 
-  for (int t = 0; t < nk; ++t) {
-    char* st  = smem + (t & 1) * CFG::STAGE_BYTES;        // stage of tile t (and of tile t+2)
-    char* nst = smem + ((t + 1) & 1) * CFG::STAGE_BYTES;  // stage of tile t+1
-    // K byte offset of tile t+2, clamped to the last tile (see sp_interval: branch-free DMA)
-    const uint32_t kb2 = kb0 + (uint32_t)min(t + 2, nk - 1) * ROW_BYTES;
-    const bool has1 = (t + 1 < nk), has2 = (t + 2 < nk);
-    // ---- interval A: MFMAs on slice 0 (set A); slice 1 of tile t streams into set B -----------------
-    sp_interval<CFG, 0>(acc, afA, bfA, afB, bfB, st + a_base_off + off1, st + b_base_off + off1, rsA, rsB, voff, wave,
-                        st, kb2, has1, has2);
-    // Y1: my A pieces of tile t+1 have landed; its B pieces and the A pieces of tile t+2 may fly on
-    wait_vmcnt<P::NJB + P::NJA>();
-    sp_sync();
-    // ---- interval B: MFMAs on slice 1 (set B); slice 0 of tile t+1 streams into set A ---------------
-    sp_interval<CFG, 1>(acc, afB, bfB, afA, bfA, nst + a_base_off + off0, nst + b_base_off + off0, rsA, rsB, voff, wave,
-                        st, kb2, has1, has2);
+  int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
+#pragma clang loop unroll(disable)
+  for (int item = 0; item < walk.count; ++item) {
+    const TileCoord tc = map_logical(g, walk.base + walk.first + item * walk.stride, BM, BN);
+    const int nk = __builtin_amdgcn_readfirstlane(tc.nk);
+    // hot loop: the issue stream stays inside this work item (steps t+2 and t+3 exist in it), so moving
+    // it on is one scalar add; nothing but the slot plan lives in this loop
+    int t = 0;
+#pragma clang loop unroll(disable)
+    for (; t + 3 < nk; ++t) {
+      SP_K_STEP();
+      iss_kbyte += ROW_BYTES;
+      ++iss_kt;
+    }
+    // last (up to) three K-steps: the issue stream may cross into the next work item
+#pragma clang loop unroll(disable)
+    for (; t < nk; ++t) {
+      SP_K_STEP();
+      SP_ISSUE_ADVANCE();
+    }
+    // ---- epilogue of this work item; the next item's first two K-steps are already in flight.  Row by
+    //      row: read 4*FN accumulators, convert, store, re-zero -- one fragment row live in VGPRs ----------
+    sp_mfma_drain();
+    const bool skip_store = (g.debug & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 row[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+      if (!skip_store)
+        store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == 2, EPI == 2 ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-
-  wait_vmcnt<0>();  // the redundant tail pieces must not outlive the workgroup's LDS allocation
-  store_tile<16, FM, FN, CFG::TM, CFG::TN, EPI == 2, EPI == 2 ? -1 : EPI>(g, tc, wave_m, wave_n, lane, acc);
+  wait_vmcnt<0>();  // redundant tail pieces must not outlive the workgroup's LDS allocation
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
+#undef SP_LOAD_ISSUE_ITEM
+#undef SP_ISSUE_ADVANCE
+#undef SP_K_STEP
 
 }  // namespace hgemm_mi355x

@@ -47,6 +47,7 @@ struct KernelEntry {
   int bm, bn, wm, wn, mi, nbuf;
   int threads, lds_bytes;
   void (*launch)(const GemmArgs&, int, hipStream_t, bool);
+  int persistent_wgs;  // > 0: the kernel walks its work items itself, launch at most this many workgroups
 };
 
 extern const KernelEntry g_kernel_table[];

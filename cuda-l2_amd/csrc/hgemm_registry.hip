@@ -22,7 +22,7 @@ namespace hgemm_mi355x {
   {"t" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m" HGEMM_STR(MI)  \
    "_s" HGEMM_STR(NB),                                                                         \
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
-   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>},
+   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0},
 #define HGEMM_PP(G, BM, BN, WM, WN, MODE)
 #define HGEMM_SP(G, BM, BN, WM, WN)
 const KernelEntry g_kernel_table[] = {
@@ -35,7 +35,7 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_PP(G, BM, BN, WM, WN, MODE)                                                        \
   {"p" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_v" HGEMM_STR(MODE), BM, \
    BN, WM, WN, 16, 4, CfgPP<BM, BN, WM, WN, MODE>::THREADS, CfgPP<BM, BN, WM, WN, MODE>::LDS_BYTES,  \
-   &launch_pp<CfgPP<BM, BN, WM, WN, MODE>>},
+   &launch_pp<CfgPP<BM, BN, WM, WN, MODE>>, 0},
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_PP
@@ -44,7 +44,8 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_PP(G, BM, BN, WM, WN, MODE)
 #define HGEMM_SP(G, BM, BN, WM, WN)                                                             \
   {"s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN), BM, BN, WM, WN, 16, 2, \
-   CfgSP<BM, BN, WM, WN>::THREADS, CfgSP<BM, BN, WM, WN>::LDS_BYTES, &launch_sp<CfgSP<BM, BN, WM, WN>>},
+   CfgSP<BM, BN, WM, WN>::THREADS, CfgSP<BM, BN, WM, WN>::LDS_BYTES, &launch_sp<CfgSP<BM, BN, WM, WN>>,      \
+   256 * (160 * 1024 / CfgSP<BM, BN, WM, WN>::LDS_BYTES)},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG

@@ -1,6 +1,6 @@
 // M=256 N=16384 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t128x256_w2x4_m32_s3, split-K 2, raster group 2  [tuned on MI355X: 180.3 us, 762 TFLOP/s]
+// plan: geometry s256x128_w2x2, split-K 2, raster group 32  [tuned on MI355X: 163.6 us, 840 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 16384, 16384, "t128x256_w2x4_m32_s3", 2, 2)
+HGEMM_MI355X_SHAPE_ENTRY(256, 16384, 16384, "s256x128_w2x2", 2, 32)

@@ -1,6 +1,6 @@
 // M=8192 N=16384 K=256  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry p256x256_w4x2_v1, split-K 1, raster group 16  [tuned on MI355X: 133.8 us, 513 TFLOP/s]
+// plan: geometry s256x128_w2x2, split-K 1, raster group 1  [tuned on MI355X: 112.7 us, 610 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 16384, 256, "p256x256_w4x2_v1", 1, 16)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 16384, 256, "s256x128_w2x2", 1, 1)

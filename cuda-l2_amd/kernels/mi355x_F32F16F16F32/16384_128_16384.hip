@@ -1,6 +1,6 @@
 // M=16384 N=128 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w2x2_m16_s4, split-K 1, raster group 2  [tuned on MI355X: 138.2 us, 497 TFLOP/s]
+// plan: geometry t128x128_w2x4_m16_s4, split-K 2, raster group 16  [tuned on MI355X: 129.9 us, 529 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 128, 16384, "t128x64_w2x2_m16_s4", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 128, 16384, "t128x128_w2x4_m16_s4", 2, 16)

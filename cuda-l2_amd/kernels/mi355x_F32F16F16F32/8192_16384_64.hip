@@ -1,6 +1,6 @@
 // M=8192 N=16384 K=64  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t256x64_w4x1_m16_s2, split-K 1, raster group 2  [tuned on MI355X: 73.4 us, 234 TFLOP/s]
+// plan: geometry s256x128_w2x2, split-K 1, raster group 1  [tuned on MI355X: 65.3 us, 263 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 16384, 64, "t256x64_w4x1_m16_s2", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 16384, 64, "s256x128_w2x2", 1, 1)

@@ -1,0 +1,91 @@
+"""ISA audit of the software-pipelined (SP) kernel family -- runs on CPU (hipcc cross-compiles gfx950).
+
+The SP kernels keep their 256 accumulators in explicitly named AGPRs (a[0..255], inline asm only).
+That is only sound while the compiler itself never touches AGPRs, never spills, and keeps the LDS-DMA
+descriptors in SGPRs; those are properties of the generated code, so they are checked on the ISA.
+"""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+CSRC = REPO / "cuda-l2_amd" / "csrc"
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _sp_groups() -> list[int]:
+    groups = sorted({int(m.group(1)) for m in re.finditer(r"^\s*HGEMM_SP\((\d+),", (CSRC / "hgemm_configs.def").read_text(), re.M)})
+    assert groups, "no HGEMM_SP entry in hgemm_configs.def"
+    return groups
+
+
+@pytest.fixture(scope="module")
+def sp_functions(tmp_path_factory):
+    if not Path(HIPCC).exists():
+        pytest.skip("hipcc not available")
+    text = ""
+    for grp in _sp_groups():
+        out = tmp_path_factory.mktemp("audit") / f"sp{grp}.s"
+        src = CSRC / f"hgemm_inst_g{grp}.hip"
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{CSRC}", f"-I{REPO / 'include'}", "-S",
+                        "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True, timeout=900)
+        text += out.read_text()
+    funcs = {}
+    for m in re.finditer(r"^(_ZN12hgemm_mi355x18hgemm_tn_sp_kernel\w+):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+        funcs[m.group(1)] = m.group(2).splitlines()
+    meta = {}
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN12hgemm_mi355x18hgemm_tn_sp_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+        meta[m.group(1)] = m.group(2)
+    assert funcs and set(funcs) == set(meta)
+    return funcs, meta
+
+
+def _outside_asm(lines):
+    inside = False
+    for ln in lines:
+        if "#ASMSTART" in ln:
+            inside = True
+        elif "#ASMEND" in ln:
+            inside = False
+        elif not inside:
+            yield ln
+
+
+def test_sp_accumulators_are_only_touched_by_the_asm_statements(sp_functions):
+    funcs, _ = sp_functions
+    for name, lines in funcs.items():
+        bad = [ln for ln in _outside_asm(lines) if re.search(r"\bv_accvgpr_|\bv_mfma_|\ba\[?\d+", ln.split(";")[0])]
+        assert not bad, f"{name}: compiler-generated AGPR access: {bad[:3]}"
+
+
+def test_sp_kernels_do_not_spill_and_leave_room_for_the_agprs(sp_functions):
+    funcs, meta = sp_functions
+    for name, lines in funcs.items():
+        assert not [ln for ln in lines if "scratch_" in ln], f"{name} uses scratch"
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta[name])
+        accum = re.search(r"\.amdhsa_accum_offset (\d+)", meta[name])
+        assert m and accum
+        assert int(m.group(1)) - int(accum.group(1)) == 256, f"{name}: expected 256 AGPRs"
+        assert int(accum.group(1)) <= 224, f"{name}: {accum.group(1)} VGPRs leaves no headroom below 256"
+        assert int(m.group(1)) <= 512
+
+
+def test_sp_k_loops_are_mfma_streams_with_scalar_dma_descriptors(sp_functions):
+    funcs, _ = sp_functions
+    for name, lines in funcs.items():
+        # K loops = innermost loops that contain MFMAs; split the function at loop headers
+        text = "\n".join(lines)
+        loops = re.split(r"This Inner Loop Header", text)[1:]
+        assert len(loops) >= 2, f"{name}: expected a hot and a tail K loop"
+        hot = loops[0].split("s_cbranch_scc")[0]
+        n_mfma = len(re.findall(r"\bv_mfma_f32_16x16x32_f16", hot))
+        assert n_mfma > 0 and n_mfma % 64 == 0, f"{name}: {n_mfma} MFMAs in the hot loop"
+        body = list(_outside_asm(hot.splitlines()))
+        # LDS-DMA with a divergent descriptor is wrapped in a waterfall loop (readfirstlane + exec masking)
+        assert not [ln for ln in body if re.search(r"v_readfirstlane|s_and_saveexec|s_cbranch_execn?z", ln)], name
+        # fragment registers are written by ds_read only; no VALU moves between the MFMAs
+        assert not [ln for ln in body if re.search(r"\bv_mov_b32|\bv_accvgpr", ln)], name
+        assert len([ln for ln in body if "buffer_load_dwordx4" in ln and " lds" in ln]) >= 8, name
