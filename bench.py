@@ -14,7 +14,8 @@ GPUs, so N > 1 runs N independent replicas (weak scaling, no collective on the d
 
 Extra objects on the JSON line:
   roofline      dominant kernel (the 4096^3 GEMM, MFMA-bound): 2MNK / mean launch duration, measured
-                live with HIP events on the launch stream inside the timed region, vs 2.5 PFLOP/s
+                live with HIP events attached to every such dispatch of the timed region (on the
+                launch stream, hipExtLaunchKernel start/stop events), vs 2.5 PFLOP/s
   cpu_baseline  the reference's CPU oracle expression (fp32 torch.matmul on the host, rounded to
                 fp16) timed on rank 0 at N=1 over a bounded sample of the same shapes
   shapes        per-shape device-timed TFLOP/s of ours and of hipBLASLt (heuristic, tn and nn) and
@@ -56,6 +57,11 @@ def load_library():
     for name in ("hgemm_rocblas_nn", "hgemm_rocblas_tn", "hgemm_hipblaslt_heuristic_nn", "hgemm_hipblaslt_heuristic_tn"):
         getattr(lib, name).argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     lib.hgemm_mi355x_config_name.restype = ctypes.c_char_p
+    lib.hgemm_mi355x_event_create.restype = vp
+    lib.hgemm_mi355x_event_destroy.argtypes = [vp]
+    lib.hgemm_mi355x_time_next_launch.argtypes = [vp, vp]
+    lib.hgemm_mi355x_event_elapsed_us.argtypes = [vp, vp]
+    lib.hgemm_mi355x_event_elapsed_us.restype = ctypes.c_double
     lib.hgemm_mi355x_strerror.restype = ctypes.c_char_p
     return lib
 
@@ -245,13 +251,19 @@ def main(argv=None):
     dominant = max(probs, key=lambda p: p.flops)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # HIP events for every dominant-kernel launch of the timed region.  They ride on the kernel's own
+    # dispatch packet (hgemm_mi355x_time_next_launch -> hipExtLaunchKernel on the launch stream), so
+    # they measure the kernel exactly as rocprofv3 does and put no marker packets between launches.
+    pool = [(lib.hgemm_mi355x_event_create(), lib.hgemm_mi355x_event_create()) for _ in range(args.steps)]
+    if any(e0 is None or e1 is None for e0, e1 in pool):
+        raise RuntimeError("hipEventCreate failed")
+
     def step(events=None):
         for p in probs:
             if events is not None and p is dominant:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                e0, e1 = pool[len(events)]
+                check(lib, lib.hgemm_mi355x_time_next_launch(e0, e1), "time_next_launch")
                 launch_ours(lib, p, stream)
-                e1.record()
                 events.append((e0, e1))
             else:
                 launch_ours(lib, p, stream)
@@ -274,7 +286,10 @@ def main(argv=None):
     step_flops = sum(p.flops for p in probs)
     elapsed, total_flops = reduce_over_ranks(elapsed, step_flops * args.steps, device)
 
-    dom_us = sum(e0.elapsed_time(e1) for e0, e1 in events) / len(events) * 1e3
+    dom_us = sum(lib.hgemm_mi355x_event_elapsed_us(e0, e1) for e0, e1 in events) / len(events)
+    for e0, e1 in pool:
+        lib.hgemm_mi355x_event_destroy(e0)
+        lib.hgemm_mi355x_event_destroy(e1)
     achieved = dominant.flops / dom_us * 1e-6
     result = {
         "metric": "HGEMM TFLOP/s", "value": round(total_flops / elapsed * 1e-12, 3), "unit": "TFLOP/s",

@@ -300,6 +300,25 @@ const char* hgemm_mi355x_strerror(int status) {
 
 int hgemm_mi355x_last_hip_error(void) { return g_last_hip_error; }
 
+// ---- measurement helpers (bench.py): kernel-exact timing without marker packets between launches ----
+void* hgemm_mi355x_event_create(void) {
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+int hgemm_mi355x_event_destroy(void* ev) { return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? HGEMM_OK : HGEMM_ERR_HIP; }
+int hgemm_mi355x_time_next_launch(void* start_event, void* stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) return HGEMM_ERR_BAD_ARG;
+  hgemm_mi355x::t_launch_timing.start = (hipEvent_t)start_event;
+  hgemm_mi355x::t_launch_timing.stop = (hipEvent_t)stop_event;
+  return HGEMM_OK;
+}
+double hgemm_mi355x_event_elapsed_us(void* start_event, void* stop_event) {
+  float ms = 0.f;
+  if (hipEventSynchronize((hipEvent_t)stop_event) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)start_event, (hipEvent_t)stop_event) != hipSuccess) return -1.0;
+  return (double)ms * 1e3;
+}
+
 int hgemm_mi355x_set_debug(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 
 const char* hgemm_mi355x_version(void) { return "hgemm_mi355x 0.1 (gfx950)"; }

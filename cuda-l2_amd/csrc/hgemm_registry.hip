@@ -16,6 +16,7 @@ namespace hgemm_mi355x {
 
 // The table holds host function pointers: keep it out of the device pass.
 #if !defined(__HIP_DEVICE_COMPILE__)
+thread_local LaunchTiming t_launch_timing;
 #define HGEMM_STR2(x) #x
 #define HGEMM_STR(x) HGEMM_STR2(x)
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)                                                    \

@@ -134,6 +134,19 @@ double hgemm_hipblaslt_autotune_best_ms(int tn);
  * N(0,1) samples (counter-based generator; `seed` makes runs reproducible). */
 int hgemm_fill_normal_f16(void* device_ptr, size_t n, unsigned long long seed, void* stream);
 
+/* ---- measurement helpers (bench.py; the reference times with torch events around each call,
+ * benchmarking_utils.py:23-31) ------------------------------------------------------------------
+ * hgemm_mi355x_time_next_launch arms a one-shot hook: the next GEMM call of the calling thread puts
+ * the two events on its main kernel's own dispatch packet, so hgemm_mi355x_event_elapsed_us returns
+ * that kernel's execution time as rocprofv3 reports it (event-record marker packets around a launch
+ * add ~6 us of queue gaps on MI355X).  For split-K plans the reduce kernel is not included.
+ * Pass (NULL, NULL) to disarm.  Events are created / destroyed with the two helpers below. */
+void* hgemm_mi355x_event_create(void);
+int hgemm_mi355x_event_destroy(void* event);
+int hgemm_mi355x_time_next_launch(void* start_event, void* stop_event);
+/* Waits for stop_event, returns microseconds between the two events (negative on error). */
+double hgemm_mi355x_event_elapsed_us(void* start_event, void* stop_event);
+
 #ifdef __cplusplus
 }
 #endif
