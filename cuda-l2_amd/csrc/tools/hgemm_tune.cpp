@@ -228,7 +228,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
 
 // ------------------------------------------------------------------------------------------------
 static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, double keep_ratio, int max_cand,
-                    bool baselines, bool sweep_group) {
+                    bool baselines, bool sweep_group, bool autotune) {
   // resumable: shapes already present in --out are skipped
   std::vector<std::string> have;
   if (out_path) {
@@ -249,6 +249,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
   if (baselines) {
     hgemm_rocblas_init();
     hgemm_hipblaslt_heuristic_init();
+    if (autotune) hgemm_hipblaslt_autotune_init();
   }
   for (const Shape& sh : shapes) {
     char key[64];
@@ -299,12 +300,30 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       lt_nn = time_us([&](Buffers& s) { hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
       lt_tn = time_us([&](Buffers& s) { hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
     }
+    double at_nn = -1, at_tn = -1;
+    int at_cand_nn = 0, at_cand_tn = 0;
+    if (baselines && autotune) {
+      // the reference's strongest baseline (cublaslt_auto_tuning): per-shape search over the heuristic
+      // candidates, time-boxed by HGEMM_AUTOTUNE_MAX_SECONDS, then timed like every other entry
+      const int reps = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
+      if (hgemm_hipblaslt_autotune_find_best_nn(sh.M, sh.N, sh.K, 0) == HGEMM_OK) {
+        at_cand_nn = hgemm_hipblaslt_autotune_candidates(0);
+        at_nn = time_us([&](Buffers& s) { hgemm_hipblaslt_autotune_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      }
+      if (hgemm_hipblaslt_autotune_find_best_tn(sh.M, sh.N, sh.K, 0) == HGEMM_OK) {
+        at_cand_tn = hgemm_hipblaslt_autotune_candidates(1);
+        at_tn = time_us([&](Buffers& s) { hgemm_hipblaslt_autotune_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      }
+    }
     fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
             sh.M, sh.N, sh.K, hgemm_mi355x_config_name(res[0].p.cfg), res[0].p.splits, res[0].p.group_m, res[0].us,
             flops / res[0].us * 1e-6);
     if (baselines)
       fprintf(out, ", \"rocblas_nn_us\": %.3f, \"rocblas_tn_us\": %.3f, \"hipblaslt_heur_nn_us\": %.3f, \"hipblaslt_heur_tn_us\": %.3f",
               rb_nn, rb_tn, lt_nn, lt_tn);
+    if (baselines && autotune)
+      fprintf(out, ", \"hipblaslt_auto_nn_us\": %.3f, \"hipblaslt_auto_tn_us\": %.3f, \"hipblaslt_auto_candidates\": [%d, %d]", at_nn, at_tn,
+              at_cand_nn, at_cand_tn);
     fprintf(out, ", \"candidates\": [");
     for (size_t i = 0; i < res.size(); ++i)
       fprintf(out, "%s{\"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"model_us\": %.2f}", i ? ", " : "",
@@ -357,13 +376,14 @@ int main(int argc, char** argv) {
   const char* cfg_name = nullptr;
   double keep = 2.5;
   int max_cand = 12, splits = 1, group = 0, reps = 20;
-  bool baselines = false, use_lib = false, sweep_group = false;
+  bool baselines = false, use_lib = false, sweep_group = false, autotune = false;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
     if (a == "--shapes" || a == "--shape") { auto v = parse_shapes(next()); shapes.insert(shapes.end(), v.begin(), v.end()); }
     else if (a == "--shape-file") { auto v = read_shape_file(next()); shapes.insert(shapes.end(), v.begin(), v.end()); }
     else if (a == "--out") out_path = next();
+    else if (a == "--autotune") autotune = true;
     else if (a == "--keep") keep = atof(next());
     else if (a == "--max-cand") max_cand = atoi(next());
     else if (a == "--baselines") baselines = true;
@@ -390,7 +410,7 @@ int main(int argc, char** argv) {
   }
   if (mode == "tune") {
     if (shapes.empty()) { fprintf(stderr, "tune needs --shapes / --shape-file\n"); return 2; }
-    return cmd_tune(shapes, out_path, keep, max_cand, baselines, sweep_group);
+    return cmd_tune(shapes, out_path, keep, max_cand, baselines, sweep_group, autotune);
   }
   if (mode == "bench") {
     if (shapes.empty()) { fprintf(stderr, "bench needs --shape\n"); return 2; }
