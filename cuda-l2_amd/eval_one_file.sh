@@ -5,9 +5,10 @@
 #   ./eval_one_file.sh --mnk 64_4096_64 --acc_precise fp32 --device_type mi355x --warmup_seconds 5 \
 #       --benchmark_seconds 10 --base_dir ./results/64_4096_64 --gpu_device_id 0 --mode offline
 #   ... --mode server --target_qps 100
+#   ... --defense          additionally run the self-audit (defense.py) before the benchmarks
 cd "$(dirname "$0")" || exit 1
 
-MODE="offline"; TARGET_QPS=""; DEVICE_TYPE="mi355x"; GPU_DEVICE_ID=0
+MODE="offline"; TARGET_QPS=""; DEVICE_TYPE="mi355x"; GPU_DEVICE_ID=0; DEFENSE=0
 while [[ $# -gt 0 ]]; do
     case $1 in
         --mnk) MNK="$2"; shift 2 ;;
@@ -19,6 +20,7 @@ while [[ $# -gt 0 ]]; do
         --gpu_device_id) GPU_DEVICE_ID="$2"; shift 2 ;;
         --mode) MODE="$2"; shift 2 ;;
         --target_qps) TARGET_QPS="$2"; shift 2 ;;
+        --defense) DEFENSE=1; shift 1 ;;
         *) echo "Unknown option: $1"; exit 1 ;;
     esac
 done
@@ -37,6 +39,14 @@ python zero_one_correctness_check.py "${COMMON[@]}"
 if [ $? -ne 0 ]; then
     echo "Error: Correctness Check failed or raised. Exiting..."
     exit 1
+fi
+
+if [ "$DEFENSE" == "1" ]; then
+    python defense.py "${COMMON[@]}"
+    if [ $? -ne 0 ]; then
+        echo "Error: defense audit failed. Exiting..."
+        exit 1
+    fi
 fi
 
 PERF_FUNCS=(hgemm_cublas_tn hgemm_cublas_nn hgemm_cublaslt_heuristic_tn hgemm_cublaslt_heuristic_nn

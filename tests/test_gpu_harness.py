@@ -102,3 +102,32 @@ def test_smoke_entry():
     import __graft_entry__
 
     __graft_entry__.smoke()
+
+
+def test_defense_audit_passes_on_the_shipped_op(kernel):
+    """f3: the reference's attack checks (defense.py), restated for the in-place 4-tensor op."""
+    import defense
+    from tools.utils import as_col_major
+
+    m, n, k = 512, 4096, 4096  # the entry point takes any shape; only the plan file is per shape
+    a = torch.randn((m, k), dtype=torch.half, device="cuda")
+    b = torch.randn((k, n), dtype=torch.half, device="cuda")
+    c = torch.zeros((m, n), dtype=torch.half, device="cuda")
+    ok, results = defense.run_all_defenses(kernel.cuda_l2_func, a, b, as_col_major(b), c)
+    assert ok, results
+    assert [r[0] for r in results] == ["stream_injection", "thread_injection", "lazy_evaluation", "precision_downgrade",
+                                       "elapsed_time_monkey_patching"]
+
+    # an op that hides its work on a side stream must be caught by the same audit
+    side = torch.cuda.Stream()
+
+    def sneaky(a, b, b_col_major, c):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                torch.matmul(a, b, out=c)
+
+    big_a = torch.randn((2048, 2048), dtype=torch.half, device="cuda")
+    big_b = torch.randn((2048, 2048), dtype=torch.half, device="cuda")
+    big_c = torch.zeros((2048, 2048), dtype=torch.half, device="cuda")
+    passed, msg, _ = defense.check_stream_injection(lambda: sneaky(big_a, big_b, None, big_c))
+    assert not passed and "Stream injection detected" in msg
