@@ -262,8 +262,6 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   const int b_base_off = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
 
   sp_reserve_agprs();
-#pragma unroll
-  for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
 
   // ---- LDS-DMA issue stream: runs two K-steps ahead of the MFMAs and crosses work-item boundaries,
   //      so the first tiles of the next output tile are in flight while the current one is stored ----
@@ -278,6 +276,10 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   SP_ISSUE_ADVANCE();
   stage_tile<CFG>(rsA, rsB, voff, smem + CFG::STAGE_BYTES, wave, iss_kbyte);
   SP_ISSUE_ADVANCE();
+  // the accumulators are cleared behind the prologue's DMA issue, in the shadow of its HBM latency
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
   wait_vmcnt<NJ>();
   __builtin_amdgcn_s_barrier();
 
@@ -317,8 +319,10 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
       f32x4 row[FN];
 #pragma unroll
       for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
+      if (item + 1 < walk.count) {  // (the last tile's accumulators are not needed again)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+        for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+      }
       if (!skip_store)
         store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == 2, EPI == 2 ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
     }
