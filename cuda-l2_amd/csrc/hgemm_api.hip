@@ -231,6 +231,9 @@ int hgemm_mi355x_set_workspace(void* device_ptr, size_t bytes) {
 int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, const void* b,
                         const void* b_col_major, void* c, int M, int N, int K, int lda, int ldb,
                         int ldc, void* stream) {
+  struct DisarmTiming {  // the timing hook is one-shot whatever path (or error return) this call takes
+    ~DisarmTiming() { hgemm_mi355x::t_launch_timing = hgemm_mi355x::LaunchTiming{}; }
+  } disarm_timing;
   if (!a || !c || M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
   if (config_id >= g_num_kernels || config_id < -1) return HGEMM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -239,7 +242,12 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, c
                     mfma_path_ok(a, b_col_major, c, M, N, K, lda, ldb, ldc);
   if (!fast) {
     if (!b) return HGEMM_ERR_BAD_ARG;
+    // the generic kernel has no dispatch-attached timing: an armed hook is served with event markers
+    const hgemm_mi355x::LaunchTiming timing = hgemm_mi355x::t_launch_timing;
+    hgemm_mi355x::t_launch_timing = hgemm_mi355x::LaunchTiming{};
+    if (timing.start) (void)hipEventRecord(timing.start, s);
     launch_generic((const f16*)a, (const f16*)b, (f16*)c, M, N, K, lda, N, ldc, s);
+    if (timing.stop) (void)hipEventRecord(timing.stop, s);
   } else {
     const KernelEntry& e = g_kernel_table[config_id];
     // 32-bit LDS-DMA offsets: (BM-1) rows * ld * 2 B + K * 2 B must stay below 4 GiB.

@@ -239,3 +239,45 @@ def test_fill_normal_statistics(g):
     L.hgemm_fill_normal_f16(y.data_ptr(), y.numel(), 42, g.stream())
     torch.cuda.synchronize()
     assert torch.equal(x, y)
+
+
+def test_dispatch_attached_timing_hook_is_one_shot_and_plausible(g):
+    """hgemm_mi355x_time_next_launch (bench.py's roofline timing): kernel-exact, one launch only."""
+    import torch
+
+    L = g.lib()
+    m = n = k = 2048
+    a = torch.randn((m, k), dtype=torch.half, device="cuda")
+    b = torch.randn((k, n), dtype=torch.half, device="cuda")
+    bt = b.t().contiguous()
+    c = torch.empty((m, n), dtype=torch.half, device="cuda")
+    call = lambda: L.hgemm_mi355x_fp32(a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, g.stream())  # noqa: E731
+    for _ in range(3):
+        assert call() == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    assert call() == 0
+    e1.record()
+    torch.cuda.synchronize()
+    marker_us = e0.elapsed_time(e1) * 1e3
+
+    h0, h1 = L.hgemm_mi355x_event_create(), L.hgemm_mi355x_event_create()
+    assert h0 and h1
+    assert L.hgemm_mi355x_time_next_launch(h0, None) != 0           # both or neither
+    assert L.hgemm_mi355x_time_next_launch(h0, h1) == 0
+    assert call() == 0
+    us = L.hgemm_mi355x_event_elapsed_us(h0, h1)
+    assert 0.3 * marker_us < us < 1.5 * marker_us, (us, marker_us)  # 2048^3 is ~25-35 us on an MI355X
+    assert call() == 0                                              # hook disarmed: the events stay as they are
+    torch.cuda.synchronize()
+    assert abs(L.hgemm_mi355x_event_elapsed_us(h0, h1) - us) < 1e-3
+    # the generic fallback (odd K) serves an armed hook with plain markers
+    a2 = torch.randn((64, 72), dtype=torch.half, device="cuda")
+    b2 = torch.randn((72, 64), dtype=torch.half, device="cuda")
+    c2 = torch.empty((64, 64), dtype=torch.half, device="cuda")
+    assert L.hgemm_mi355x_time_next_launch(h0, h1) == 0
+    assert L.hgemm_mi355x_fp32(a2.data_ptr(), b2.data_ptr(), b2.t().contiguous().data_ptr(), c2.data_ptr(), 64, 64, 72, g.stream()) == 0
+    assert L.hgemm_mi355x_event_elapsed_us(h0, h1) > 0
+    torch.testing.assert_close(c2.float(), (a2.float() @ b2.float()).half().float(), rtol=2e-3, atol=2e-2)
+    assert L.hgemm_mi355x_event_destroy(h0) == 0 and L.hgemm_mi355x_event_destroy(h1) == 0
