@@ -75,8 +75,8 @@ void build_tuned_index() {
 // MI355X constants (MI355X_MICROARCH.md): 256 CUs, 4 SIMDs/CU, 160 KiB LDS/CU, 512 regs/lane/SIMD.
 constexpr int    kCUs          = 256;
 constexpr double kLaunchUs     = 2.0;    // host launch + dispatch of one kernel
-constexpr double kBoundaryUs   = 1.8;    // dependent kernel boundary (split-K combine)
-constexpr double kHbmBytesUs   = 5.0e6;  // ~5 TB/s sustained for mixed read/write
+constexpr double kBoundaryUs   = 3.7;    // dependent kernel boundary + launch of the split-K combine (fitted)
+constexpr double kHbmBytesUs   = 4.6e6;  // ~4.6 TB/s sustained for mixed read/write (fitted)
 constexpr double kCuFlopUs     = 4069.0 * 2000.0;  // fp16 MFMA flop per CU per us at ~2.0 GHz
 
 // Raster group height.  What matters for L2 reuse is the set of tiles an XCD runs CONCURRENTLY
@@ -105,18 +105,22 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   conc = (int)std::max<long>(1, std::min<long>(conc, (wgs + kCUs - 1) / kCUs));
   const long rounds = (wgs + (long)kCUs * conc - 1) / ((long)kCUs * conc);
   const int ksteps = (K / splits + BK - 1) / BK;
-  // MFMA efficiency falls with the wave tile's operand reuse (LDS bytes per flop).
+  // Constants fitted to the measured candidates of the 1000-shape tune (tuning/r01_grid_tune_*.jsonl):
+  // geomean regret of the model's pick against the measured best 2.0 % (3.9 % before the fit).
+  // MFMA efficiency falls with the wave tile's operand reuse (LDS bytes per flop); the software-
+  // pipelined family ('s', one wave per SIMD) sustains ~1.5x the classic schedule's rate.
+  const char family = e.name[0];
   const double reuse = (double)tm * tn / (tm + tn);
-  // measured on MI355X: the 32x32x16 MFMA variants trail the 16x16x32 ones by 5-15 % in this structure
-  const double eff = 0.62 * std::min(1.0, reuse / 42.0) * (e.mi == 32 ? 0.88 : 1.0);
+  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (family == 's' ? 1.47 : family == 'p' ? 1.12 : 1.0);
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
-  const double step_lat = (e.nbuf >= 3 ? 0.22 : 0.40);  // barrier + LDS-DMA round trip floor
-  const double main_us = rounds * (1.2 + ksteps * std::max(step_tp, step_lat));
+  // per-K-step latency floor: barrier + LDS-DMA round trip (double-buffered rings expose all of it)
+  const double step_lat = family == 's' ? 0.40 : (e.nbuf >= 3 ? 0.33 : 0.74);
+  const double main_us = rounds * (1.0 + ksteps * std::max(step_tp, step_lat));
   double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
   double extra = 0.0;
   if (splits > 1) {
     bytes += 8.0 * (double)M * N * splits;
-    extra = kBoundaryUs + 4.0 * (double)M * N * (splits + 0.5) / kHbmBytesUs;
+    extra = kBoundaryUs + 4.0 * (double)M * N * (splits + 0.5) / kHbmBytesUs + 0.17 * splits;
   }
   return kLaunchUs + std::max(main_us, bytes / kHbmBytesUs) + extra;
 }

@@ -116,6 +116,7 @@ static double median(std::vector<float> v) {
 }
 
 struct Plan { int cfg, splits, group_m; double model_us; };
+static bool g_plan_only = false;  // tune --plan-only
 
 // Time one callable over rotating buffer sets; returns median microseconds.
 template <class F>
@@ -263,7 +264,15 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     std::vector<Buffers> sets(nsets);
     for (int i = 0; i < nsets; ++i) alloc_set(sets[i], sh, 77 + i, baselines);
 
-    std::vector<Plan> cands = candidates(sh, keep_ratio, max_cand);
+    std::vector<Plan> cands;
+    if (g_plan_only) {  // report mode: time the library's own plan (tuned table / model) against the baselines
+      Plan p{0, 1, 1, 0.0};
+      hgemm_mi355x_plan(sh.M, sh.N, sh.K, &p.cfg, &p.splits, &p.group_m);
+      p.model_us = p.cfg >= 0 ? hgemm_mi355x_model_us(p.cfg, p.splits, sh.M, sh.N, sh.K) : 0.0;
+      cands.push_back(p);
+    } else {
+      cands = candidates(sh, keep_ratio, max_cand);
+    }
     struct Res { Plan p; double us; };
     std::vector<Res> res;
     for (const Plan& p : cands) {
@@ -384,6 +393,7 @@ int main(int argc, char** argv) {
     else if (a == "--shape-file") { auto v = read_shape_file(next()); shapes.insert(shapes.end(), v.begin(), v.end()); }
     else if (a == "--out") out_path = next();
     else if (a == "--autotune") autotune = true;
+    else if (a == "--plan-only") g_plan_only = true;
     else if (a == "--keep") keep = atof(next());
     else if (a == "--max-cand") max_cand = atoi(next());
     else if (a == "--baselines") baselines = true;
