@@ -271,11 +271,48 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, c
     g.splits = splits;
     g.group_m = std::max(1, std::min(group_m, g.tiles_m));
     g.debug = g_debug_flags;
+    g.tail_first = 0; g.tail_tiles = 0;
     const long grid = (long)g.tiles_m * g.tiles_n * splits;
     if (grid > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
+    g.items = (int)grid;
     if (splits > 1) {
       int st = ensure_workspace(hgemm_mi355x_workspace_bytes(M, N, splits), &g.partial);
       if (st != HGEMM_OK) return st;
+    }
+    // Hybrid schedule for the persistent family (stream-K's data-parallel + tail form): when the tile
+    // count is not a multiple of the resident workgroups, the last partial round would keep most CUs
+    // idle for a whole tile time.  Instead the full rounds run as they are and the `tail` leftover
+    // tiles are cut along K into floor(G / tail) slices each, one slice per workgroup, combined by a
+    // small reduce over compact fp32 slabs.  (7168^3 with 256x256 tiles: 784 = 3 x 256 + 16.)
+    const long G = e.persistent_wgs;
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    if (G > 0 && splits == 1 && tiles > G && tiles % G != 0 && !(g_debug_flags & 32)) {
+      const long tail = tiles % G, full = tiles - tail;
+      int S = (int)std::min<long>(G / tail, ksteps / 4);   // >= 4 K-steps per slice
+      if (S >= 2) {
+        const int per = (ksteps + S - 1) / S;
+        S = (ksteps + per - 1) / per;
+        // Worth it when it beats the partial round it replaces.  Measured on MI355X: a round with few
+        // tiles runs at ~0.6x of a full round's tile time (no contention), and the tail pass costs its
+        // K slice plus ~25 us of prologue / epilogue / two extra launches / combine
+        // (7168^3: 702 -> 661 us, 4352^2 x 4096: 175 -> 149 us; 10000^2 x 1024 would lose 7 %).
+        const double tile_us = model_us(e, e.bm, e.bn, K, 1) - kLaunchUs;
+        if (0.6 * tile_us - tile_us / S > 25.0) {
+          GemmArgs t = g;
+          t.tail_first = (int)full; t.tail_tiles = (int)tail; t.splits = S; t.k_chunk = per * BK;
+          t.items = (int)tail * S;
+          // (a caller-lent workspace that is too small just means: no hybrid schedule)
+          if (ensure_workspace((size_t)t.items * e.bm * e.bn * sizeof(float), &t.partial) == HGEMM_OK) {
+            g.items = (int)full;
+            e.launch(g, (int)std::min<long>(full, G), s, false);
+            e.launch(t, (int)std::min<long>(t.items, G), s, true);
+            launch_tail_reduce(t, e.bm, e.bn, s);
+            hipError_t err2 = hipGetLastError();
+            if (err2 != hipSuccess) { g_last_hip_error = (int)err2; return HGEMM_ERR_HIP; }
+            return HGEMM_OK;
+          }
+        }
+      }
     }
     // persistent families walk their work items themselves: one resident wave of workgroups
     const long launch_grid = (e.persistent_wgs > 0) ? std::min<long>(grid, e.persistent_wgs) : grid;

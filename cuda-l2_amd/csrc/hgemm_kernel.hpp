@@ -74,6 +74,12 @@ struct GemmArgs {
   int splits;
   int tiles_m, tiles_n;
   int group_m;     // rasterisation group height in tiles
+  // Work-item space of this launch.  Normal launch: items = splits * tiles, item = split * tiles + tile.
+  // Tail pass of the hybrid schedule (tail_tiles > 0): only tiles [tail_first, tail_first + tail_tiles)
+  // are processed, each cut into `splits` K slices; item = slice * tail_tiles + (tile - tail_first) and
+  // its fp32 partial goes to the COMPACT slab partial[item][BM][BN].
+  int items;       // number of work items of this launch
+  int tail_first, tail_tiles;
   int debug;       // ablation only (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
                    // epilogue stores, bit 2 cut every tile's K loop to two steps, bit 3 every tile stores to tile (0,0)
 };
@@ -111,13 +117,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 // The dispatcher places block b on XCD b % 8 (observed, used for speed only); the remap hands
 // each XCD one contiguous run of logical tile ids, and the grouped raster makes that run a
 // compact patch of the tile grid, so the A/B panels a patch shares are hit in that XCD's L2.
-struct TileCoord { int split, m0, n0, k_begin, nk; };
+struct TileCoord {
+  int split, m0, n0, k_begin, nk;
+  float* slab;   // fp32 partial destination of element (m0, n0) for split-K / tail items
+  int slab_ld;   // its row stride in floats
+};
 
 // logical work-item id (after the XCD remap) -> (split, tile origin, K range), grouped raster
 __device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int BM, int BN) {
   const int tiles = g.tiles_m * g.tiles_n;
-  const int split = bid / tiles;
-  const int t_id  = bid - split * tiles;
+  int split, t_id;
+  if (g.tail_tiles > 0) {
+    split = bid / g.tail_tiles;
+    t_id  = g.tail_first + (bid - split * g.tail_tiles);
+  } else {
+    split = bid / tiles;
+    t_id  = bid - split * tiles;
+  }
   const int gsz   = g.group_m * g.tiles_n;
   const int grp   = t_id / gsz;
   const int first_m = grp * g.group_m;
@@ -130,6 +146,13 @@ __device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int
   tc.k_begin = split * g.k_chunk;
   tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin) / BK;
   if (g.debug & 4) tc.nk = min(tc.nk, 2);
+  if (g.tail_tiles > 0) {
+    tc.slab = g.partial + (size_t)bid * ((size_t)BM * BN);
+    tc.slab_ld = BN;
+  } else {
+    tc.slab = g.partial + ((size_t)split * g.M + tc.m0) * g.N + tc.n0;
+    tc.slab_ld = g.N;
+  }
   return tc;
 }
 
@@ -217,7 +240,7 @@ __device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoor
       const int n = tc.n0 + wave_n * TN + j * MI + q * 8 + ln;
       if (m < g.M && n < g.N) {
         if constexpr (SPLITK) {
-          float* dst = g.partial + ((size_t)tc.split * g.M + m) * g.N + n;
+          float* dst = tc.slab + (size_t)(m - tc.m0) * tc.slab_ld + (n - tc.n0);
           f32x4 o = {row[j][q * 4 + 0], row[j][q * 4 + 1], row[j][q * 4 + 2], row[j][q * 4 + 3]};
           *(f32x4*)dst = o;
         } else {

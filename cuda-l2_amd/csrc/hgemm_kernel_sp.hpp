@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   const int wave_n = wave % CFG::WN;
 
   // persistent walk over this workgroup's work items ((split, tile) pairs)
-  const ItemWalk walk = persistent_walk(g.tiles_m * g.tiles_n * g.splits);
+  const ItemWalk walk = persistent_walk(g.items);
   if (walk.count == 0) return;
 
   // fragment offsets of the two K=32 slices inside a stage (same image as hgemm_tn_kernel)

@@ -74,6 +74,7 @@ extern const int g_num_kernels;
 
 void launch_splitk_reduce(const float* partial, f16* C, int M, int N, int ldc, int splits,
                           hipStream_t stream);
+void launch_tail_reduce(const GemmArgs& g, int BM, int BN, hipStream_t stream);
 void launch_generic(const f16* A, const f16* B, f16* C, int M, int N, int K, int lda, int ldb,
                     int ldc, hipStream_t stream);
 

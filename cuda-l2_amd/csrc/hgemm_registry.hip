@@ -86,6 +86,28 @@ __global__ void __launch_bounds__(256) hgemm_splitk_reduce_kernel(const float* _
   }
 }
 
+// Combine of the hybrid schedule's tail pass: C tile t = fp16( sum_s partial[s * tail_tiles + t][BM][BN] ),
+// slices added in K order.  One workgroup per (tail tile, 16-row band); the tile origin comes from the same
+// raster map the GEMM kernel used.
+__global__ void __launch_bounds__(256) hgemm_tail_reduce_kernel(const GemmArgs g, int BM, int BN) {
+  const int bands = BM / 16;
+  const int t = blockIdx.x / bands, band = blockIdx.x % bands;
+  const TileCoord tc = map_logical(g, t, BM, BN);  // slice 0 of tail tile t: gives (m0, n0)
+  const size_t slab = (size_t)BM * BN, stride = slab * g.tail_tiles;
+  const float* base = g.partial + (size_t)t * slab;
+  const int quads_per_row = BN / 4;
+  for (int q = threadIdx.x; q < 16 * quads_per_row; q += blockDim.x) {
+    const int r = band * 16 + q / quads_per_row, c = (q % quads_per_row) * 4;
+    const int m = tc.m0 + r, n = tc.n0 + c;
+    if (m >= g.M || n >= g.N) continue;
+    const float* p = base + (size_t)r * BN + c;
+    f32x4 s = *(const f32x4*)p;
+    for (int k = 1; k < g.splits; ++k) s += *(const f32x4*)(p + (size_t)k * stride);
+    f16x4 o = {(f16)s[0], (f16)s[1], (f16)s[2], (f16)s[3]};
+    *(f16x4*)(g.C + (size_t)m * g.ldc + n) = o;
+  }
+}
+
 // Any-shape / any-alignment fallback (one output per thread, fp32 accumulate).  Correctness
 // net for shapes the MFMA path does not accept (K % 64 != 0, unaligned views); never tuned.
 __global__ void __launch_bounds__(256) hgemm_generic_kernel(const f16* __restrict__ A,
@@ -110,6 +132,10 @@ void launch_splitk_reduce(const float* partial, f16* C, int M, int N, int ldc, i
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(hgemm_splitk_reduce_kernel, dim3(grid), dim3(threads), 0, stream, partial, C, M, N,
                      ldc, splits);
+}
+
+void launch_tail_reduce(const GemmArgs& g, int BM, int BN, hipStream_t stream) {
+  hipLaunchKernelGGL(hgemm_tail_reduce_kernel, dim3(g.tail_tiles * (BM / 16)), dim3(256), 0, stream, g, BM, BN);
 }
 
 void launch_generic(const f16* A, const f16* B, f16* C, int M, int N, int K, int lda, int ldb,

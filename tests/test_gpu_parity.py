@@ -281,3 +281,22 @@ def test_dispatch_attached_timing_hook_is_one_shot_and_plausible(g):
     assert L.hgemm_mi355x_event_elapsed_us(h0, h1) > 0
     torch.testing.assert_close(c2.float(), (a2.float() @ b2.float()).half().float(), rtol=2e-3, atol=2e-2)
     assert L.hgemm_mi355x_event_destroy(h0) == 0 and L.hgemm_mi355x_event_destroy(h1) == 0
+
+
+@pytest.mark.parametrize("shape", [(4352, 4352, 4096), (4300, 4400, 4096)])
+def test_hybrid_tail_schedule_is_exact_on_zero_one_inputs(g, shape):
+    """Persistent family, tile count not a multiple of the resident workgroups: full rounds + K-split
+    tail tiles + compact-slab combine (hgemm_api.hip).  Integer-valued inputs make every fp32 sum exact,
+    so the result must be bit-identical to the CPU product whatever the summation order."""
+    m, n, k = shape
+    rng = np.random.default_rng(7)
+    a = (rng.random((m, k)) < 0.25).astype(np.float16)
+    b = (rng.random((k, n)) < 0.25).astype(np.float16)
+    truth = (torch.from_numpy(a).float() @ torch.from_numpy(b).float()).half().numpy()
+    assert float(np.abs(truth).max()) <= 2047
+    names = g.config_names()
+    for cfg in ("s256x256_w2x2", "s128x256_w2x2"):
+        got = g.gemm(a, b, plan=(names.index(cfg), 1, 4))
+        assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), cfg
+    # the library's own plan for the shape (whatever it picks) agrees as well
+    assert np.array_equal(g.gemm(a, b).view(np.uint16), truth.view(np.uint16))
