@@ -1,6 +1,6 @@
 // M=1024 N=8192 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry s256x128_w2x2, split-K 1, raster group 8  [tuned on MI355X: 116.9 us, 1175 TFLOP/s]
+// plan: geometry s128x256_w2x2, split-K 1, raster group 32  [tuned on MI355X: 121.5 us, 1131 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 8192, "s256x128_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 8192, "s128x256_w2x2", 1, 32)

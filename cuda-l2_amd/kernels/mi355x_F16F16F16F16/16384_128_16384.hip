@@ -1,5 +1,5 @@
 // M=16384 N=128 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x4_m16_s4, split-K 2, raster group 16  [tuned on MI355X: 129.9 us, 529 TFLOP/s]
+// plan: geometry t128x128_w2x4_m16_s4, split-K 2, raster group 16  [tuned on MI355X: 134.1 us, 512 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

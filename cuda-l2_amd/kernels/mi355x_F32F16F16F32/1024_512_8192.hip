@@ -1,6 +1,6 @@
 // M=1024 N=512 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 4, raster group 8  [tuned on MI355X: 20.9 us, 411 TFLOP/s]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 4, raster group 2  [tuned on MI355X: 21.2 us, 406 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 512, 8192, "t64x64_w2x2_m16_s4", 4, 8)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 512, 8192, "t64x64_w2x2_m16_s4", 4, 2)

@@ -1,6 +1,6 @@
 // M=128 N=16384 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x256_w2x4_m32_s3, split-K 4, raster group 2  [tuned on MI355X: 91.2 us, 565 TFLOP/s]
+// plan: geometry s128x256_w2x2, split-K 4, raster group 1  [tuned on MI355X: 92.2 us, 559 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 16384, 12288, "t128x256_w2x4_m32_s3", 4, 2)
+HGEMM_MI355X_SHAPE_ENTRY(128, 16384, 12288, "s128x256_w2x2", 4, 1)

@@ -1,5 +1,5 @@
 // M=8192 N=256 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry s256x128_w2x2, split-K 4, raster group 8  [tuned on MI355X: 67.4 us, 764 TFLOP/s]
+// plan: geometry s256x128_w2x2, split-K 4, raster group 8  [tuned on MI355X: 68.0 us, 758 TFLOP/s]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
