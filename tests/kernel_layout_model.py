@@ -321,3 +321,47 @@ def wide_epilogue_columns(fn: int):
             assert cols == list(range(n_base, n_base + 8)), (lane, cols, n_base)
             out[(j, lane)] = cols
     return out
+
+
+# ---- persistent family (hgemm_kernel_sp.hpp): work-item walk, hybrid tail partition, slot plan ---------
+def persistent_walk(bid: int, grid: int, total_items: int):
+    """Mirror of persistent_walk(): logical item ids of workgroup `bid` of a `grid`-workgroup launch, in
+    the order it processes them (hgemm_kernel.hpp)."""
+    xcd, j = bid % 8, bid // 8
+    nwg_x = grid // 8 + (1 if xcd < grid % 8 else 0)
+    q, r = total_items // 8, total_items % 8
+    items_x = q + (1 if xcd < r else 0)
+    base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+    count = (items_x - j + nwg_x - 1) // nwg_x if j < items_x else 0
+    return [base + j + i * nwg_x for i in range(count)]
+
+
+def hybrid_partition(tiles: int, ksteps: int, G: int):
+    """Host side of the hybrid schedule (hgemm_api.hip): -> (full_items, tail, S, steps_per_slice) or None
+    when the plain persistent launch is used.  The profitability test is not modelled (always split)."""
+    if not (G > 0 and tiles > G and tiles % G):
+        return None
+    tail = tiles % G
+    S = min(G // tail, ksteps // 4)
+    if S < 2:
+        return None
+    per = -(-ksteps // S)
+    S = -(-ksteps // per)
+    return tiles - tail, tail, S, per
+
+
+def tail_item(bid: int, tail_first: int, tail_tiles: int, per: int, ksteps: int):
+    """Tail-pass item id -> (tile id, first K-step, number of K-steps), as map_logical() does."""
+    split, t = divmod(bid, tail_tiles)
+    k0 = split * per
+    return tail_first + t, k0, min(ksteps, k0 + per) - k0
+
+
+def sp_plan(FM: int, FN: int, NJA: int, NJB: int, RS: int = 2):
+    """Slot plan of one K-step of family 's' (SpPlan): which slots carry DMA pieces and sync points."""
+    T = FM * FN
+    X1, Y2 = RS * FM + 4, T // 2
+    a_slots = [X1 + (a * (T - 1 - X1)) // NJA for a in range(NJA)]
+    b_slots = [2 + (b * (T - 3)) // NJB for b in range(NJB)]
+    return {"T": T, "X1": X1, "Y2": Y2, "a_slots": a_slots, "b_slots": b_slots,
+            "NB1": sum(s < Y2 for s in b_slots)}

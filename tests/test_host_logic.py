@@ -214,3 +214,41 @@ def test_sweep_shard_and_merge(tmp_path):
     assert rep["mean_speedup_vs_torch.matmul"] == pytest.approx(1.0)
     csv = Path(rep["csv"]).read_text().splitlines()
     assert csv[0].startswith("mnk,torch.matmul,rocBLAS-tn") and csv[1].startswith(shapes[0] + ",1.500")
+
+
+def test_tuned_table_rows_are_what_the_planner_returns(lib):
+    """Every committed tuned plan is served verbatim by hgemm_mi355x_plan (names resolve, no stale rows)."""
+    lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    rows = [json.loads(line) for line in (PKG / "tuning" / "r01_grid_tune_mi355x.jsonl").read_text().splitlines() if line.strip()]
+    assert len(rows) == 1000
+    for r in rows[::7]:
+        m, n, k = (int(x) for x in r["mnk"].split("_"))
+        cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.hgemm_mi355x_plan(m, n, k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm)) == 0
+        assert lib.hgemm_mi355x_config_name(cfg.value).decode() == r["best"]["config"], r["mnk"]
+        assert (sp.value, gm.value) == (r["best"]["splits"], r["best"]["group_m"]), r["mnk"]
+
+
+def test_analytic_model_picks_near_optimal_plans_on_the_measured_candidates(lib):
+    """Off-grid shapes are planned by the analytic model.  Its constants are fitted to the measured
+    candidates of the tuning run; this pins the fit: the model's pick among the measured (config, splits)
+    pairs of every grid shape must stay within a few percent of the measured best (geomean regret)."""
+    import math
+
+    lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    regrets = []
+    for line in (PKG / "tuning" / "r01_grid_tune_run2_mi355x.jsonl").read_text().splitlines():
+        r = json.loads(line)
+        m, n, k = (int(x) for x in r["mnk"].split("_"))
+        measured = {}
+        for c in r["candidates"]:
+            key = (c["config"], c["splits"])
+            measured[key] = min(measured.get(key, 1e30), c["us"])
+        ids = {key: lib.hgemm_mi355x_config_by_name(key[0].encode()) for key in measured}
+        assert min(ids.values()) >= 0
+        pick = min(measured, key=lambda key: lib.hgemm_mi355x_model_us(ids[key], key[1], m, n, k))
+        regrets.append(measured[pick] / min(measured.values()))
+    geomean = math.exp(sum(map(math.log, regrets)) / len(regrets))
+    assert len(regrets) == 1000
+    assert geomean < 1.04, geomean          # 1.02 on the run the constants were fitted to
+    assert sorted(regrets)[int(0.9 * len(regrets))] < 1.15

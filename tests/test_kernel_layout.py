@@ -114,3 +114,68 @@ def test_wide_epilogue_permlane_mapping(fn):
     for l15 in range(16):  # every C row of the fragment: each of the fn*16 columns stored exactly once
         seen = sorted(c for (j, lane), cs in cols.items() if lane & 15 == l15 for c in cs)
         assert seen == list(range(fn * 16))
+
+
+@pytest.mark.parametrize("grid,total", [(256, 256), (256, 1024), (256, 784), (256, 1000), (200, 4097), (8, 3), (256, 17), (128, 129)])
+def test_persistent_walk_partitions_the_items(grid, total):
+    """Every work item is processed by exactly one workgroup; XCD x owns the contiguous range map_block
+    would give it, and an XCD's concurrently processed items are consecutive ids (compact patch)."""
+    seen = []
+    for bid in range(grid):
+        items = klm.persistent_walk(bid, grid, total)
+        seen += items
+        assert all(b > a for a, b in zip(items, items[1:]))
+    assert sorted(seen) == list(range(total))
+    for xcd in range(min(8, grid)):
+        first_round = sorted(klm.persistent_walk(b, grid, total)[0] for b in range(xcd, grid, 8) if klm.persistent_walk(b, grid, total))
+        assert first_round == list(range(first_round[0], first_round[0] + len(first_round))) if first_round else True
+    if grid >= total:  # one item per workgroup: identical to the non-persistent XCD remap
+        for bid in range(total):
+            got = klm.persistent_walk(bid, total, total)
+            assert got == [klm.remap_block(bid, total)]
+
+
+@pytest.mark.parametrize("tiles,ksteps,G", [(784, 112, 256), (576, 96, 256), (289, 64, 256), (1600, 16, 256), (300, 8, 256), (380, 40, 256)])
+def test_hybrid_tail_partition_covers_every_tile_and_k_step_once(tiles, ksteps, G):
+    part = klm.hybrid_partition(tiles, ksteps, G)
+    assert part is not None
+    full, tail, S, per = part
+    assert full % G == 0 and full + tail == tiles and tail * S <= G and 2 <= S
+    assert (S - 1) * per < ksteps <= S * per          # no empty slice, K covered
+    cover = {}
+    for bid in range(tail * S):
+        t, k0, nk = klm.tail_item(bid, full, tail, per, ksteps)
+        assert full <= t < tiles and nk >= 1
+        cover.setdefault(t, []).append((k0, nk))
+    assert sorted(cover) == list(range(full, tiles))
+    for t, parts in cover.items():
+        parts.sort()
+        assert parts[0][0] == 0 and sum(nk for _, nk in parts) == ksteps
+        assert all(a[0] + a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    # compact slabs: slab index = tail item id, all distinct
+    assert len({bid for bid in range(tail * S)}) == tail * S
+
+
+def test_hybrid_schedule_is_not_used_when_it_cannot_help():
+    assert klm.hybrid_partition(768, 112, 256) is None      # whole rounds only
+    assert klm.hybrid_partition(200, 112, 256) is None      # a single partial round: nothing to shorten
+    assert klm.hybrid_partition(300, 4, 256) is None        # K too short to slice (< 4 steps per slice)
+    assert klm.hybrid_partition(511, 40, 256) is None       # tail of 255 tiles: nearly a full round already
+
+
+@pytest.mark.parametrize("bm,bn", [(256, 256), (256, 128), (128, 256)])
+def test_sp_slot_plan_counts_match_the_waits(bm, bn):
+    """The counted vmcnt waits of family 's' assume: every DMA piece of a K-step has its own MFMA slot,
+    A pieces go out after X1 in interval A, B pieces in interval B, NB1 of them ahead of Y2."""
+    nw, wm, wn = 4, 2, 2
+    FM, FN = bm // wm // 16, bn // wn // 16
+    NJA, NJB = bm // 8 // nw, bn // 8 // nw
+    p = klm.sp_plan(FM, FN, NJA, NJB)
+    T = p["T"]
+    assert len(set(p["a_slots"])) == NJA and len(set(p["b_slots"])) == NJB
+    assert all(p["X1"] <= s < T for s in p["a_slots"]) and all(2 <= s < T for s in p["b_slots"])
+    assert 2 * FM <= p["Y2"] and p["Y2"] + 2 * FN <= T and 2 * (FM + FN) <= T
+    assert 0 < p["NB1"] < NJB
+    # Y1 wait: the A pieces of step+1 must have landed while B(step+1) and A(step+2) may fly: NJB + NJA younger
+    # Y2 wait: B(step+1) landed while A(step+2) and the NB1 early B(step+2) pieces may fly
+    assert NJA + NJB <= 63 and NJA + p["NB1"] <= 63          # vmcnt is a 6-bit counter
