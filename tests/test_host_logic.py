@@ -252,3 +252,46 @@ def test_analytic_model_picks_near_optimal_plans_on_the_measured_candidates(lib)
     assert len(regrets) == 1000
     assert geomean < 1.04, geomean          # 1.02 on the run the constants were fitted to
     assert sorted(regrets)[int(0.9 * len(regrets))] < 1.15
+
+
+def test_report_tools_on_synthetic_inputs(tmp_path):
+    """tools/plot_speedups.py, tools/tune_report.py and tools/pmc_summary.py parse what the GPU runs write."""
+    sys.path.insert(0, str(PKG))
+    from tools import plot_speedups, tune_report
+
+    cols = ["torch.matmul", "rocBLAS-tn", "rocBLAS-nn", "rocBLAS-max", "hipBLASLt-heuristic-tn", "hipBLASLt-heuristic-nn",
+            "hipBLASLt-heuristic-max", "hipBLASLt-auto-tuning-tn", "hipBLASLt-auto-tuning-nn", "hipBLASLt-auto-tuning-max"]
+    csv_path = tmp_path / "s.csv"
+    csv_path.write_text("mnk," + ",".join(cols) + "\n64_64_64," + ",".join(["1.5"] * 10) + "\n128_128_128," + ",".join(["1.1"] * 10) + "\n")
+    means, n = plot_speedups.mean_speedups(str(csv_path))
+    assert n == 2 and all(abs(m - 1.3) < 1e-9 for m in means)
+    rows = [{"mnk": "64_64_64", "best": {"config": "t32x32_w1x1_m16_s4", "splits": 1, "group_m": 1, "us": 5.0},
+             "rocblas_nn_us": 10.0, "rocblas_tn_us": 9.0, "hipblaslt_heur_nn_us": 8.0, "hipblaslt_heur_tn_us": 7.5, "candidates": []},
+            {"mnk": "128_128_128", "best": {"config": "t32x32_w1x1_m16_s4", "splits": 1, "group_m": 1, "us": 6.0},
+             "rocblas_nn_us": 6.0, "rocblas_tn_us": 6.0, "hipblaslt_heur_nn_us": 3.0, "hipblaslt_heur_tn_us": 12.0, "candidates": [],
+             "hipblaslt_auto_nn_us": 2.0, "hipblaslt_auto_tn_us": 4.0}]
+    jl = tmp_path / "t.jsonl"
+    jl.write_text("".join(json.dumps(r) + "\n" for r in rows))
+    xs, ys = plot_speedups.grid_points(str(jl))
+    assert xs == [2.0 * 64 ** 3, 2.0 * 128 ** 3] and ys == [1.5, 0.5]
+    rep = tune_report.main(str(jl), 1)
+    assert abs(rep["geomean_speedup_vs_hipblaslt_heuristic_max"] - (1.5 * 0.5) ** 0.5) < 1e-9
+    assert rep["autotune_shapes"] == 1 and abs(rep["geomean_speedup_vs_hipblaslt_autotune_max"] - 2.0 / 6.0) < 1e-9
+    plot_speedups.main(["--csv", str(csv_path), "--grid", str(jl), "--out", str(tmp_path / "f.png")])
+    assert (tmp_path / "f.png").stat().st_size > 1000
+
+    # rocprofv3 pass directories as tools/pmc_sweep.sh writes them
+    d = tmp_path / "pmc" / "pass0" / "box"
+    d.mkdir(parents=True)
+    (d / "1_counter_collection.csv").write_text(
+        "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+        "1,k_sp_kernel,GRBM_GUI_ACTIVE,1600000\n1,k_sp_kernel,SQ_VALU_MFMA_BUSY_CYCLES,102400000\n1,k_sp_kernel,SQ_BUSY_CYCLES,1\n"
+        "1,k_sp_kernel,FETCH_SIZE,1000\n1,k_sp_kernel,WRITE_SIZE,500\n2,other,FETCH_SIZE,7\n")
+    (d / "1_kernel_trace.csv").write_text("Dispatch_Id,Kernel_Name,Start_Timestamp,End_Timestamp\n1,k_sp_kernel,0,100000\n2,other,0,5\n")
+    out = subprocess.run([sys.executable, str(PKG / "tools" / "pmc_summary.py"), str(tmp_path / "pmc"), "--kernel", "sp_kernel",
+                          "--mnk", "4096_4096_4096"], check=True, capture_output=True, text=True).stdout
+    summ = json.loads(out)
+    assert summ["derived"]["avg_kernel_us_profiled"] == 100.0
+    assert abs(summ["derived"]["effective_clock_ghz"] - 2.0) < 1e-9            # 1.6e6 cycles / 8 XCDs / 100 us
+    assert abs(summ["derived"]["mfma_pipe_busy_frac"] - 0.5) < 1e-9            # 1.024e8 / (1024 SIMDs * 2e5 cycles)
+    assert summ["dominant_kernel"]["hbm_bytes_per_launch"] == (2 * 1000 + 500) * 1024
