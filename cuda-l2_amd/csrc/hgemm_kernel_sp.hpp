@@ -24,7 +24,7 @@
 //       Y1  end of A     vmcnt + barrier: the A pieces of tile t+1 have landed (their B pieces and the
 //                        A pieces of t+2 may still fly); also frees the B region of stage s
 //       B[0, FM)         ds_read slice 0 A fragments of tile t+1 -> set A
-//       B[2, T)          DMA: the B pieces of tile t+2 -> stage s
+//       B[2, T/2)        DMA: the B pieces of tile t+2 -> stage s (early: the latest piece sets the wait)
 //       Y2  B[T/2]       vmcnt + barrier: the B pieces of tile t+1 have landed
 //       B[T/2, T/2+FN)   ds_read slice 0 B fragments of tile t+1 -> set A
 //
@@ -38,6 +38,15 @@
 #pragma once
 
 #include "hgemm_kernel.hpp"
+
+// DMA issue windows of the slot plan in 64ths of an interval (see SpPlan::AEND / BEND).  Measured: B pieces
+// issued in the first half of interval B (33) instead of across all of it (61): 8192^3 883 -> 862 us.
+#ifndef HGEMM_SP_AEND_64
+#define HGEMM_SP_AEND_64 63
+#endif
+#ifndef HGEMM_SP_BEND_64
+#define HGEMM_SP_BEND_64 33
+#endif
 
 namespace hgemm_mi355x {
 
@@ -94,10 +103,14 @@ struct SpPlan {
   static constexpr int RS = 2;                               // one fragment read every RS MFMA slots
   static constexpr int X1 = RS * FM + 4;                     // slot of interval A that carries the X1 sync
   static constexpr int Y2 = T / 2;                           // slot of interval B that carries the Y2 sync
+  // last slot (exclusive) that may carry an A / B piece: issuing the pieces early in their interval
+  // lengthens the flight time of the latest ones (they are the ones a sync point waits for)
+  static constexpr int AEND = (T * HGEMM_SP_AEND_64) / 64 > X1 + NJA ? (T * HGEMM_SP_AEND_64) / 64 : X1 + NJA;
+  static constexpr int BEND = (T * HGEMM_SP_BEND_64) / 64 > 2 + NJB ? (T * HGEMM_SP_BEND_64) / 64 : 2 + NJB;
   // A piece a (0..NJA-1) fires behind slot X1 + a*(T-1-X1)/NJA of interval A
-  static constexpr int a_slot(int a) { return X1 + (a * (T - 1 - X1)) / NJA; }
+  static constexpr int a_slot(int a) { return X1 + (a * (AEND - X1)) / NJA; }
   // B piece b (0..NJB-1) fires behind slot 2 + b*(T-3)/NJB of interval B
-  static constexpr int b_slot(int b) { return 2 + (b * (T - 3)) / NJB; }
+  static constexpr int b_slot(int b) { return 2 + (b * (BEND - 2)) / NJB; }
   static constexpr int a_at(int slot) { for (int a = 0; a < NJA; ++a) if (a_slot(a) == slot) return a; return -1; }
   static constexpr int b_at(int slot) { for (int b = 0; b < NJB; ++b) if (b_slot(b) == slot) return b; return -1; }
   static constexpr int b_before_y2() { int c = 0; for (int b = 0; b < NJB; ++b) c += b_slot(b) < Y2; return c; }

@@ -362,6 +362,7 @@ def sp_plan(FM: int, FN: int, NJA: int, NJB: int, RS: int = 2):
     T = FM * FN
     X1, Y2 = RS * FM + 4, T // 2
     a_slots = [X1 + (a * (T - 1 - X1)) // NJA for a in range(NJA)]
-    b_slots = [2 + (b * (T - 3)) // NJB for b in range(NJB)]
+    bend = max((T * 33) // 64, 2 + NJB)   # B pieces go out in the first half of interval B
+    b_slots = [2 + (b * (bend - 2)) // NJB for b in range(NJB)]
     return {"T": T, "X1": X1, "Y2": Y2, "a_slots": a_slots, "b_slots": b_slots,
             "NB1": sum(s < Y2 for s in b_slots)}

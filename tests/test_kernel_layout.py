@@ -175,7 +175,7 @@ def test_sp_slot_plan_counts_match_the_waits(bm, bn):
     assert len(set(p["a_slots"])) == NJA and len(set(p["b_slots"])) == NJB
     assert all(p["X1"] <= s < T for s in p["a_slots"]) and all(2 <= s < T for s in p["b_slots"])
     assert 2 * FM <= p["Y2"] and p["Y2"] + 2 * FN <= T and 2 * (FM + FN) <= T
-    assert 0 < p["NB1"] < NJB
+    assert 0 < p["NB1"] <= NJB
     # Y1 wait: the A pieces of step+1 must have landed while B(step+1) and A(step+2) may fly: NJB + NJA younger
     # Y2 wait: B(step+1) landed while A(step+2) and the NB1 early B(step+2) pieces may fly
     assert NJA + NJB <= 63 and NJA + p["NB1"] <= 63          # vmcnt is a 6-bit counter
