@@ -10,36 +10,74 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 using namespace hgemm_mi355x;
 
 namespace {
 
 int g_last_hip_error = 0;
-int g_debug_flags = 0;  // HGEMM_MI355X_DEBUG (ablation experiments of the tuner; never set in production)
+#ifdef HGEMM_ABLATION
+int g_debug_flags = 0;  // tuner-only build: hgemm_mi355x_set_debug
+#endif
 
 // ---- split-K workspace ------------------------------------------------------------------------
+// One buffer per (device, stream): two GEMMs on different streams (or devices) never share slabs or
+// arrival counters.  Layout: [kCounterBytes of tile arrival counters, zero between launches][fp32 slabs].
+// Growth happens on first use of a bigger plan only (hipFree of the old buffer synchronises the device,
+// so no kernel can still be using it); steady state is a mutex + a short linear search.
+constexpr size_t kCounterBytes = (size_t)256 << 10;             // 65536 tiles
+constexpr size_t kMaxFusedTiles = kCounterBytes / sizeof(unsigned);
+struct Workspace {
+  int device; hipStream_t stream;
+  char* ptr; size_t bytes;      // whole allocation (counters + slabs)
+};
 std::mutex g_ws_mutex;
-void*  g_ws_ptr   = nullptr;
-size_t g_ws_bytes = 0;
-bool   g_ws_owned = false;
+std::vector<Workspace> g_ws;
+// caller-lent buffer (hgemm_mi355x_set_workspace): used for every stream of the device that was current
+// when it was lent; the caller promises not to run GEMMs concurrently on several streams then.
+char*  g_lent_ptr = nullptr;
+size_t g_lent_bytes = 0;
+int    g_lent_device = -1;
 
-int ensure_workspace(size_t bytes, float** out) {
+// slab_bytes of fp32 slab space (+ counters) for a launch on `stream`; HGEMM_ERR_NO_WORKSPACE when a lent
+// buffer is too small or the allocation fails -- the caller then degrades to a plan that needs none.
+constexpr int HGEMM_ERR_NO_WORKSPACE_INTERNAL = -100;
+int ensure_workspace(size_t slab_bytes, hipStream_t stream, float** slabs, unsigned** counters) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return HGEMM_ERR_HIP;
+  const size_t need = kCounterBytes + slab_bytes;
   std::lock_guard<std::mutex> lk(g_ws_mutex);
-  if (bytes > g_ws_bytes) {
-    if (!g_ws_owned && g_ws_ptr != nullptr) return HGEMM_ERR_BAD_ARG;  // lent buffer too small
-    if (g_ws_ptr) {
-      hipError_t e = hipFree(g_ws_ptr);
+  if (g_lent_ptr) {
+    if (dev != g_lent_device || need > g_lent_bytes) return HGEMM_ERR_NO_WORKSPACE_INTERNAL;
+    *counters = (unsigned*)g_lent_ptr;
+    *slabs = (float*)(g_lent_ptr + kCounterBytes);
+    return HGEMM_OK;
+  }
+  Workspace* w = nullptr;
+  for (Workspace& e : g_ws)
+    if (e.device == dev && e.stream == stream) { w = &e; break; }
+  if (!w) {
+    g_ws.push_back({dev, stream, nullptr, 0});
+    w = &g_ws.back();
+  }
+  if (need > w->bytes) {
+    if (w->ptr) {
+      hipError_t e = hipFree(w->ptr);   // device-synchronising: nothing in flight still reads the old slabs
       if (e != hipSuccess) { g_last_hip_error = (int)e; return HGEMM_ERR_HIP; }
-      g_ws_ptr = nullptr; g_ws_bytes = 0;
+      w->ptr = nullptr; w->bytes = 0;
     }
     // Grow geometrically (min 64 MiB) so a sweep over shapes re-allocates O(log) times.
-    size_t want = std::max(bytes, std::max<size_t>(g_ws_bytes * 2, (size_t)64 << 20));
-    hipError_t e = hipMalloc(&g_ws_ptr, want);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; g_ws_ptr = nullptr; return HGEMM_ERR_HIP; }
-    g_ws_bytes = want; g_ws_owned = true;
+    const size_t want = std::max(need, std::max<size_t>(w->bytes * 2, (size_t)64 << 20));
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_last_hip_error = (int)e; return HGEMM_ERR_NO_WORKSPACE_INTERNAL; }
+    e = hipMemsetAsync(p, 0, kCounterBytes, stream);   // ordered in front of the first launch that uses them
+    if (e != hipSuccess) { (void)hipFree(p); g_last_hip_error = (int)e; return HGEMM_ERR_HIP; }
+    w->ptr = (char*)p; w->bytes = want;
   }
-  *out = (float*)g_ws_ptr;
+  *counters = (unsigned*)w->ptr;
+  *slabs = (float*)(w->ptr + kCounterBytes);
   return HGEMM_OK;
 }
 
@@ -199,8 +237,8 @@ int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* gro
     *config_id = lo->cfg; *splits = lo->splits; *group_m = lo->group_m;
     return HGEMM_OK;
   }
-  if (K % BK != 0 || (N & 3) != 0) {  // generic kernel
-    *config_id = -1; *splits = 1; *group_m = 1;
+  if (K % BK != 0 || (N & 3) != 0) {  // register-staged any-shape MFMA kernel (hgemm_kernel_rg.hpp)
+    *config_id = HGEMM_CONFIG_RAGGED; *splits = 1; *group_m = 1;
     return HGEMM_OK;
   }
   model_plan(M, N, K, config_id, splits, group_m);
@@ -219,79 +257,124 @@ int hgemm_mi355x_default_group(int config_id, int M, int N) {
 }
 
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits) {
-  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  // upper bound over both split-K forms and every tile size (<= 256): counters + tile-padded fp32 slabs
+  if ((splits & HGEMM_SPLITK_MASK) <= 1) return 0;
+  const size_t mp = ((size_t)M + 255) / 256 * 256, np = ((size_t)N + 255) / 256 * 256;
+  return kCounterBytes + (size_t)(splits & HGEMM_SPLITK_MASK) * mp * np * sizeof(float);
 }
 
 int hgemm_mi355x_set_workspace(void* device_ptr, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_ws_mutex);
-  if (g_ws_owned && g_ws_ptr) {
-    hipError_t e = hipFree(g_ws_ptr);
+  if (device_ptr) {
+    if (bytes < kCounterBytes) return HGEMM_ERR_BAD_ARG;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return HGEMM_ERR_HIP;
+    hipError_t e = hipMemset(device_ptr, 0, kCounterBytes);   // arrival counters start at zero
     if (e != hipSuccess) { g_last_hip_error = (int)e; return HGEMM_ERR_HIP; }
+    g_lent_device = dev;
   }
-  g_ws_ptr = device_ptr; g_ws_bytes = device_ptr ? bytes : 0; g_ws_owned = false;
+  g_lent_ptr = (char*)device_ptr; g_lent_bytes = device_ptr ? bytes : 0;
   return HGEMM_OK;
 }
 
-int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, const void* b,
+int hgemm_mi355x_release_workspaces(void) {
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  int rc = HGEMM_OK;
+  for (Workspace& w : g_ws)
+    if (w.ptr && hipFree(w.ptr) != hipSuccess) rc = HGEMM_ERR_HIP;
+  g_ws.clear();
+  return rc;
+}
+
+int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* a, const void* b,
                         const void* b_col_major, void* c, int M, int N, int K, int lda, int ldb,
                         int ldc, void* stream) {
   struct DisarmTiming {  // the timing hook is one-shot whatever path (or error return) this call takes
     ~DisarmTiming() { hgemm_mi355x::t_launch_timing = hgemm_mi355x::LaunchTiming{}; }
   } disarm_timing;
   if (!a || !c || M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
-  if (config_id >= g_num_kernels || config_id < -1) return HGEMM_ERR_BAD_ARG;
+  if (config_id >= g_num_kernels || config_id < HGEMM_CONFIG_RAGGED) return HGEMM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
+  const bool two_pass = (splits_arg & HGEMM_SPLITK_TWO_PASS) != 0;
+  int splits = splits_arg & HGEMM_SPLITK_MASK;
 
-  const bool fast = config_id >= 0 && b_col_major &&
-                    mfma_path_ok(a, b_col_major, c, M, N, K, lda, ldb, ldc);
+  GemmArgs g;
+  g.A = (const f16*)a; g.Bt = (const f16*)b_col_major; g.C = (f16*)c; g.partial = nullptr; g.counters = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.k_chunk = K; g.splits = 1; g.tiles_m = g.tiles_n = 1; g.group_m = 1; g.items = 1;
+  g.tail_first = 0; g.tail_tiles = 0;
+#ifdef HGEMM_ABLATION
+  g.debug = g_debug_flags;
+#endif
+
+  bool fast = config_id >= 0 && b_col_major && mfma_path_ok(a, b_col_major, c, M, N, K, lda, ldb, ldc);
+  if (fast) {
+    // 32-bit LDS-DMA offsets: (BM-1) rows * ld * 2 B + K * 2 B must stay below 4 GiB; beyond that the
+    // register-staged kernel (64-bit addressing) takes over instead of an error.
+    const KernelEntry& e = g_kernel_table[config_id];
+    if ((double)e.bm * lda * 2.0 + K * 2.0 >= 4294967296.0 || (double)e.bn * ldb * 2.0 + K * 2.0 >= 4294967296.0)
+      fast = false;
+  }
   if (!fast) {
-    if (!b) return HGEMM_ERR_BAD_ARG;
-    // the generic kernel has no dispatch-attached timing: an armed hook is served with event markers
-    const hgemm_mi355x::LaunchTiming timing = hgemm_mi355x::t_launch_timing;
-    hgemm_mi355x::t_launch_timing = hgemm_mi355x::LaunchTiming{};
-    if (timing.start) (void)hipEventRecord(timing.start, s);
-    launch_generic((const f16*)a, (const f16*)b, (f16*)c, M, N, K, lda, N, ldc, s);
-    if (timing.stop) (void)hipEventRecord(timing.stop, s);
+    if (config_id != HGEMM_CONFIG_GENERIC && b_col_major) {
+      if ((long)((M + 63) / 64) * ((N + 63) / 64) > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
+      launch_ragged(g, s, timing_slot(true, true));
+    } else {
+      if (!b) return HGEMM_ERR_BAD_ARG;
+      launch_generic((const f16*)a, (const f16*)b, (f16*)c, M, N, K, lda, N, ldc, s, timing_slot(true, true));
+    }
   } else {
     const KernelEntry& e = g_kernel_table[config_id];
-    // 32-bit LDS-DMA offsets: (BM-1) rows * ld * 2 B + K * 2 B must stay below 4 GiB.
-    if ((double)e.bm * lda * 2.0 + K * 2.0 >= 4294967296.0 ||
-        (double)e.bn * ldb * 2.0 + K * 2.0 >= 4294967296.0)
-      return HGEMM_ERR_TOO_LARGE;
-    GemmArgs g;
-    g.A = (const f16*)a; g.Bt = (const f16*)b_col_major; g.C = (f16*)c; g.partial = nullptr;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.tiles_m = (M + e.bm - 1) / e.bm;
     g.tiles_n = (N + e.bn - 1) / e.bn;
+    const long tiles = (long)g.tiles_m * g.tiles_n;
     const int ksteps = K / BK;
     splits = std::max(1, std::min(splits, ksteps));
     const int steps_per_split = (ksteps + splits - 1) / splits;
     splits = (ksteps + steps_per_split - 1) / steps_per_split;  // no empty split
-    g.k_chunk = steps_per_split * BK;
-    g.splits = splits;
     g.group_m = std::max(1, std::min(group_m, g.tiles_m));
-    g.debug = g_debug_flags;
-    g.tail_first = 0; g.tail_tiles = 0;
-    const long grid = (long)g.tiles_m * g.tiles_n * splits;
-    if (grid > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
-    g.items = (int)grid;
+    if (tiles * splits > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
+    // Split-K: single-launch ("fused") by default, two-pass (slabs + combine kernel) on request or when the
+    // tile count exceeds the counter block.  No workspace (lent buffer too small, allocation failed) means
+    // no split-K: the plan degrades to splits = 1 instead of failing.
+    int epi = EPI_C16;
     if (splits > 1) {
-      int st = ensure_workspace(hgemm_mi355x_workspace_bytes(M, N, splits), &g.partial);
-      if (st != HGEMM_OK) return st;
+      const bool fused = !two_pass && tiles <= (long)kMaxFusedTiles;
+      const size_t slab_bytes = fused ? (size_t)tiles * splits * e.bm * e.bn * sizeof(float)
+                                      : (size_t)splits * M * N * sizeof(float);
+      unsigned* counters = nullptr;
+      const int st = ensure_workspace(slab_bytes, s, &g.partial, &counters);
+      if (st == HGEMM_OK) {
+        epi = fused ? EPI_FUSED : EPI_SLAB;
+        if (fused) g.counters = counters;
+      } else if (st == HGEMM_ERR_NO_WORKSPACE_INTERNAL) {
+        splits = 1; g.partial = nullptr;
+      } else {
+        return st;
+      }
     }
+    const int per = (ksteps + splits - 1) / splits;
+    g.k_chunk = per * BK;
+    g.splits = splits;
+    const long grid = tiles * splits;
+    g.items = (int)grid;
     // Hybrid schedule for the persistent family (stream-K's data-parallel + tail form): when the tile
     // count is not a multiple of the resident workgroups, the last partial round would keep most CUs
     // idle for a whole tile time.  Instead the full rounds run as they are and the `tail` leftover
     // tiles are cut along K into floor(G / tail) slices each, one slice per workgroup, combined by a
     // small reduce over compact fp32 slabs.  (7168^3 with 256x256 tiles: 784 = 3 x 256 + 16.)
     const long G = e.persistent_wgs;
-    const long tiles = (long)g.tiles_m * g.tiles_n;
-    if (G > 0 && splits == 1 && tiles > G && tiles % G != 0 && !(g_debug_flags & 32)) {
+#ifdef HGEMM_ABLATION
+    const bool hybrid_ok = !(g_debug_flags & 32);
+#else
+    const bool hybrid_ok = true;
+#endif
+    if (G > 0 && splits == 1 && tiles > G && tiles % G != 0 && hybrid_ok) {
       const long tail = tiles % G, full = tiles - tail;
       int S = (int)std::min<long>(G / tail, ksteps / 4);   // >= 4 K-steps per slice
       if (S >= 2) {
-        const int per = (ksteps + S - 1) / S;
-        S = (ksteps + per - 1) / per;
+        const int per_t = (ksteps + S - 1) / S;
+        S = (ksteps + per_t - 1) / per_t;
         // Worth it when it beats the partial round it replaces.  Measured on MI355X: a round with few
         // tiles runs at ~0.6x of a full round's tile time (no contention), and the tail pass costs its
         // K slice plus ~25 us of prologue / epilogue / two extra launches / combine
@@ -299,14 +382,15 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, c
         const double tile_us = model_us(e, e.bm, e.bn, K, 1) - kLaunchUs;
         if (0.6 * tile_us - tile_us / S > 25.0) {
           GemmArgs t = g;
-          t.tail_first = (int)full; t.tail_tiles = (int)tail; t.splits = S; t.k_chunk = per * BK;
+          t.tail_first = (int)full; t.tail_tiles = (int)tail; t.splits = S; t.k_chunk = per_t * BK;
           t.items = (int)tail * S;
-          // (a caller-lent workspace that is too small just means: no hybrid schedule)
-          if (ensure_workspace((size_t)t.items * e.bm * e.bn * sizeof(float), &t.partial) == HGEMM_OK) {
+          unsigned* unused = nullptr;
+          // (no workspace just means: no hybrid schedule)
+          if (ensure_workspace((size_t)t.items * e.bm * e.bn * sizeof(float), s, &t.partial, &unused) == HGEMM_OK) {
             g.items = (int)full;
-            e.launch(g, (int)std::min<long>(full, G), s, false);
-            e.launch(t, (int)std::min<long>(t.items, G), s, true);
-            launch_tail_reduce(t, e.bm, e.bn, s);
+            e.launch(g, (int)std::min<long>(full, G), s, EPI_C16, timing_slot(true, false));
+            e.launch(t, (int)std::min<long>(t.items, G), s, EPI_SLAB, timing_slot(false, false));
+            launch_tail_reduce(t, e.bm, e.bn, s, timing_slot(false, true));
             hipError_t err2 = hipGetLastError();
             if (err2 != hipSuccess) { g_last_hip_error = (int)err2; return HGEMM_ERR_HIP; }
             return HGEMM_OK;
@@ -316,8 +400,8 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m, const void* a, c
     }
     // persistent families walk their work items themselves: one resident wave of workgroups
     const long launch_grid = (e.persistent_wgs > 0) ? std::min<long>(grid, e.persistent_wgs) : grid;
-    e.launch(g, (int)launch_grid, s, splits > 1);
-    if (splits > 1) launch_splitk_reduce(g.partial, g.C, M, N, ldc, splits, s);
+    e.launch(g, (int)launch_grid, s, epi, timing_slot(true, epi != EPI_SLAB));
+    if (epi == EPI_SLAB) launch_splitk_reduce(g.partial, g.C, M, N, ldc, splits, s, timing_slot(false, true));
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) { g_last_hip_error = (int)err; return HGEMM_ERR_HIP; }
@@ -368,8 +452,11 @@ double hgemm_mi355x_event_elapsed_us(void* start_event, void* stop_event) {
   return (double)ms * 1e3;
 }
 
+#ifdef HGEMM_ABLATION
+// tuner-only library build (lib_ablation/): results are garbage by construction, never shipped
 int hgemm_mi355x_set_debug(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
+#endif
 
-const char* hgemm_mi355x_version(void) { return "hgemm_mi355x 0.1 (gfx950)"; }
+const char* hgemm_mi355x_version(void) { return "hgemm_mi355x 0.2 (gfx950)"; }
 
 }  // extern "C"

@@ -385,5 +385,11 @@ int hgemm_hipblaslt_autotune_tn(const void* a, const void* bt, void* c, int M, i
 }
 int hgemm_hipblaslt_autotune_candidates(int tn) { return (tn ? g_auto.tn : g_auto.nn).candidates; }
 double hgemm_hipblaslt_autotune_best_ms(int tn) { return (tn ? g_auto.tn : g_auto.nn).best_ms; }
+int hgemm_hipblaslt_compute16_fallback(int which, int tn) {
+  LtContext& ctx = which ? g_auto : g_heur;
+  const LtProblem& p = tn ? ctx.tn : ctx.nn;
+  if (p.M == 0) return -1;
+  return (p.acc == HGEMM_ACC_FP16 && !p.compute16) ? 1 : 0;
+}
 
 }  // extern "C"

@@ -8,26 +8,17 @@ namespace hgemm_mi355x {
 #define HGEMM_INST_3(...)
 #undef HGEMM_INST_2
 #define HGEMM_INST_2(BM, BN, WM, WN, MI, NB) \
-  template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, bool);
+  template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB) HGEMM_INST_##G(BM, BN, WM, WN, MI, NB)
-#define HGEMM_PPINST_0(...)
-#define HGEMM_PPINST_1(...)
-#define HGEMM_PPINST_2(...)
-#define HGEMM_PPINST_3(...)
-#undef HGEMM_PPINST_2
-#define HGEMM_PPINST_2(BM, BN, WM, WN, MODE) \
-  template void launch_pp<CfgPP<BM, BN, WM, WN, MODE>>(const GemmArgs&, int, hipStream_t, bool);
-#define HGEMM_PP(G, BM, BN, WM, WN, MODE) HGEMM_PPINST_##G(BM, BN, WM, WN, MODE)
 #define HGEMM_SPINST_0(...)
 #define HGEMM_SPINST_1(...)
 #define HGEMM_SPINST_2(...)
 #define HGEMM_SPINST_3(...)
 #undef HGEMM_SPINST_2
-#define HGEMM_SPINST_2(BM, BN, WM, WN) \
-  template void launch_sp<CfgSP<BM, BN, WM, WN>>(const GemmArgs&, int, hipStream_t, bool);
-#define HGEMM_SP(G, BM, BN, WM, WN) HGEMM_SPINST_##G(BM, BN, WM, WN)
+#define HGEMM_SPINST_2(BM, BN, WM, WN, MI) \
+  template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_SP(G, BM, BN, WM, WN, MI) HGEMM_SPINST_##G(BM, BN, WM, WN, MI)
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
-#undef HGEMM_PP
 #undef HGEMM_SP
 }  // namespace hgemm_mi355x

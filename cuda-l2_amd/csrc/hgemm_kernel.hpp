@@ -80,9 +80,27 @@ struct GemmArgs {
   // its fp32 partial goes to the COMPACT slab partial[item][BM][BN].
   int items;       // number of work items of this launch
   int tail_first, tail_tiles;
-  int debug;       // ablation only (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
+  // Single-launch split-K (EPI_FUSED): one arrival counter per output tile (zero before the launch, reset
+  // by the last arriver) and compact per-item slabs partial[item][BM*BN] in the kernel's own lane order.
+  unsigned* counters;
+#ifdef HGEMM_ABLATION
+  int debug;       // tuner-only build (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
                    // epilogue stores, bit 2 cut every tile's K loop to two steps, bit 3 every tile stores to tile (0,0)
+#endif
 };
+
+// Ablation switches exist only in the tuner's -DHGEMM_ABLATION build of the library (lib_ablation/);
+// in the shipping library they fold to `false` and the branches disappear.
+#ifdef HGEMM_ABLATION
+#define HGEMM_DBG(g, bit) (((g).debug & (bit)) != 0)
+#else
+#define HGEMM_DBG(g, bit) false
+#endif
+
+// Epilogue modes shared by the kernel families.
+constexpr int EPI_C16    = 0;  // fp16 C, written directly (splits == 1)
+constexpr int EPI_SLAB   = 1;  // fp32 partials to [splits][M][N] (or compact tail slabs); a second kernel combines
+constexpr int EPI_FUSED  = 2;  // single-launch split-K: fp32 partials + arrival counter, the last arriver combines
 
 // Compile-time geometry of one kernel instantiation.
 template <int BM_, int BN_, int WM_, int WN_, int MI_, int NBUF_>
@@ -119,6 +137,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // compact patch of the tile grid, so the A/B panels a patch shares are hit in that XCD's L2.
 struct TileCoord {
   int split, m0, n0, k_begin, nk;
+  int tile, item;   // output-tile id (raster order) and work-item id (split * tiles + tile)
   float* slab;   // fp32 partial destination of element (m0, n0) for split-K / tail items
   int slab_ld;   // its row stride in floats
 };
@@ -141,12 +160,14 @@ __device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int
   const int tin   = t_id - grp * gsz;
   TileCoord tc;
   tc.split = split;
+  tc.tile = t_id;
+  tc.item = bid;
   tc.m0 = (first_m + tin % gm) * BM;
   tc.n0 = (tin / gm) * BN;
   tc.k_begin = split * g.k_chunk;
   tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin) / BK;
-  if (g.debug & 4) tc.nk = min(tc.nk, 2);
-  if (g.tail_tiles > 0) {
+  if (HGEMM_DBG(g, 4)) tc.nk = min(tc.nk, 2);
+  if (g.tail_tiles > 0 || g.counters != nullptr) {   // compact per-item slabs (tail pass, fused split-K)
     tc.slab = g.partial + (size_t)bid * ((size_t)BM * BN);
     tc.slab_ld = BN;
   } else {
@@ -211,7 +232,7 @@ __device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoor
                       (((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0));
     if (wide) {
       const int q = lane >> 4;
-      const int m = ((g.debug & 8) ? 0 : tc.m0) + wave_m * TM + i * 16 + (lane & 15);
+      const int m = (HGEMM_DBG(g, 8) ? 0 : tc.m0) + wave_m * TM + i * 16 + (lane & 15);
 #pragma unroll
       for (int j = 0; j < FN; j += 2) {
         using h2 = __attribute__((ext_vector_type(2))) _Float16;
@@ -219,7 +240,7 @@ __device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoor
         const h2 b01 = {(f16)row[j + 1][0], (f16)row[j + 1][1]}, b23 = {(f16)row[j + 1][2], (f16)row[j + 1][3]};
         const auto r0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, b01), false, false);
         const auto r1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a23), __builtin_bit_cast(unsigned, b23), false, false);
-        const int n = ((g.debug & 8) ? 0 : tc.n0) + wave_n * TN + 16 * (j + (q & 1)) + 8 * (q >> 1);
+        const int n = (HGEMM_DBG(g, 8) ? 0 : tc.n0) + wave_n * TN + 16 * (j + (q & 1)) + 8 * (q >> 1);
         if (m < g.M && n < g.N) {
           using u4 = __attribute__((ext_vector_type(4))) unsigned;
           const u4 o = {r0[0], r1[0], r0[1], r1[1]};
@@ -256,7 +277,7 @@ __device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoor
 template <int MI, int FM, int FN, int TM, int TN, bool SPLITK, int WIDE = -1, class ACC>
 __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& tc, int wave_m,
                                            int wave_n, int lane, ACC (&acc)[FM][FN]) {
-  if (g.debug & 2) return;
+  if (HGEMM_DBG(g, 2)) return;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     // keep the accumulator -> VGPR traffic of one fragment row together: without the fence the
@@ -264,6 +285,41 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& t
     __builtin_amdgcn_sched_barrier(0);
     store_tile_row<MI, FN, TM, TN, SPLITK, WIDE>(g, tc, wave_m, wave_n, lane, i, acc[i]);
   }
+}
+
+// ---- single-launch split-K ("fused"; replaces the reference's atomicAdd split-K, a100_F32F16F16F32/
+// 64_256_16384.cu:149-152, and its per-call memset + convert kernels) ---------------------------------------
+// Every (split, tile) work item writes its fp32 partial to its own compact slab in the kernel's LANE ORDER
+// (quad x of thread tid at slab[(x * THREADS + tid) * 4]: every store instruction is one contiguous 1 KiB
+// per wave), publishes it with one agent-scope release, and draws a ticket from the tile's arrival counter.
+// The workgroup that draws the last ticket acquires once, adds the `splits` slabs IN SPLIT ORDER (so the
+// result does not depend on arrival order: deterministic, unlike atomics) and writes the fp16 tile.  Nobody
+// waits for anybody, so the scheme needs no co-residency and cannot deadlock; placement only affects speed.
+// The last arriver resets the counter, so the counters are zero between launches (the host zeroes them once
+// at allocation).  Protocol = cdna_hip_programming.md section 6, guideline 16 (fence first, ticket second).
+template <int THREADS>
+__device__ __forceinline__ float* fused_slot(float* slab, int x, int tid) {
+  return slab + ((size_t)x * THREADS + tid) * 4;
+}
+
+// Called by every thread of the workgroup after its slab stores were issued.  `lds_flag` is a word of the
+// kernel's (single) LDS array that no in-flight LDS-DMA targets.  True in every thread of the last arriver.
+__device__ __forceinline__ bool fused_publish_and_vote(const GemmArgs& g, int tile, volatile unsigned* lds_flag, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my slab stores have left the wave
+  __syncthreads();                                    // ... and so have every other wave's
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restates the post-write-back wait where hipcc may drop it
+    const unsigned old = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (old + 1u == (unsigned)g.splits);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *lds_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *lds_flag != 0u;
 }
 
 // The buffer-resource builtins only exist in the device pass; the host pass just needs the
@@ -289,7 +345,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsA, __amdgpu_
 
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <class CFG, bool SPLITK>
+template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NBUF = CFG::NBUF;
@@ -376,7 +432,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // all waves' pieces of tile t landed; stage `wr` is free again
 
-    if (t + NBUF - 1 < nk && !(g.debug & 1)) {
+    if (t + NBUF - 1 < nk && !HGEMM_DBG(g, 1)) {
       stage_tile<CFG>(rsA, rsB, voff, smem + wr * CFG::STAGE_BYTES, wave, kbyte);
       kbyte += ROW_BYTES;
     }
@@ -407,7 +463,40 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
 
   // ---- epilogue ----------------------------------------------------------------------------------
   (void)split;
-  store_tile<MI, FM, FN, CFG::TM, CFG::TN, SPLITK>(g, tc, wave_m, wave_n, lane, acc);
+  if constexpr (EPI == EPI_FUSED) {
+    constexpr int NQ = (MI == 16) ? 1 : 4;   // f32x4 quads per accumulator tile
+    const size_t slab_elems = (size_t)BM * BN;
+    float* mine = g.partial + (size_t)tc.item * slab_elems;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+          *(f32x4*)fused_slot<CFG::THREADS>(mine, (i * FN + j) * NQ + q, tid) = v;
+        }
+    if (!fused_publish_and_vote(g, tc.tile, (volatile unsigned*)smem, tid)) return;
+    // last arriver: slabs of this tile are item = s * tiles + tile, s = 0 .. splits-1, added in that order
+    const size_t stride = (size_t)g.tiles_m * g.tiles_n * slab_elems;
+    const float* base = g.partial + (size_t)tc.tile * slab_elems;
+    for (int sidx = 0; sidx < g.splits; ++sidx) {
+      float* sl = const_cast<float*>(base) + (size_t)sidx * stride;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const f32x4 v = *(const f32x4*)fused_slot<CFG::THREADS>(sl, (i * FN + j) * NQ + q, tid);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = (sidx == 0) ? v[e] : acc[i][j][q * 4 + e] + v[e];
+          }
+    }
+    store_tile<MI, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
+  } else {
+    store_tile<MI, FM, FN, CFG::TM, CFG::TN, EPI == EPI_SLAB>(g, tc, wave_m, wave_n, lane, acc);
+  }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

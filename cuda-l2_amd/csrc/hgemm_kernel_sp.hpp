@@ -35,6 +35,11 @@
 //     ahead of the MFMAs ACROSS work items, so the first two K-steps of the next output tile are in
 //     flight while the current tile is converted and stored: no workgroup launch and no exposed
 //     prologue latency per tile (measured: +12..20 % on K <= 1024 with M, N >= 8192, +2 % on 8192^3).
+//   * two MFMA shapes: MI = 16 (v_mfma_f32_16x16x32_f16, 64 MFMAs per interval) and MI = 32
+//     (v_mfma_f32_32x32x16_f16: two K=16 slices per interval, 32 MFMAs of 32 cycles).  Same LDS image, same
+//     fragment bytes and the same slot plan in units of MFMA slots; the 32x32 form has half the MFMA issues
+//     (its micro-benchmark ceiling is 11 % higher, MI355X_MICROARCH.md) and twice the issue room per slot for
+//     the ds_read / LDS-DMA instructions that ride between the MFMAs.
 #pragma once
 
 #include "hgemm_kernel.hpp"
@@ -50,12 +55,20 @@
 
 namespace hgemm_mi355x {
 
-// geometry = Cfg<BM, BN, WM, WN, 16, 2>; DMA pieces issued per MFMA group are derived below
-template <int BM_, int BN_, int WM_, int WN_>
-struct CfgSP : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
-  using Base = Cfg<BM_, BN_, WM_, WN_, 16, 2>;
+// geometry = Cfg<BM, BN, WM, WN, MI, 2>; DMA pieces issued per MFMA group are derived below.
+// An interval covers K = 32 of the stage: one 16x16x32 slice or two 32x32x16 slices.
+template <int BM_, int BN_, int WM_, int WN_, int MI_ = 16>
+struct CfgSP : Cfg<BM_, BN_, WM_, WN_, MI_, 2> {
+  using Base = Cfg<BM_, BN_, WM_, WN_, MI_, 2>;
+  static constexpr int SL  = (MI_ == 16) ? 1 : 2;          // MFMA k-slices per interval
+  static constexpr int NFA = Base::FM * SL;                // A / B fragment reads (ds_read_b128) per interval
+  static constexpr int NFB = Base::FN * SL;
+  static constexpr int T   = Base::FM * Base::FN * SL;     // MFMA slots per interval
+  static constexpr int ACC = (MI_ == 16) ? 4 : 16;         // accumulator registers per MFMA tile
+  static constexpr int FLAG_OFF = Base::LDS_BYTES;         // LDS word of the fused split-K vote (behind the stages)
   static_assert(Base::NI % Base::NW == 0, "even DMA piece split");
-  static_assert(Base::FM * Base::FN >= Base::NJ, "one MFMA slot per interleaved DMA piece");
+  static_assert(T >= Base::NJ, "one MFMA slot per interleaved DMA piece");
+  static_assert(Base::FM * Base::FN * ACC <= 256, "accumulators live in a0..a255");
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -78,6 +91,13 @@ __device__ __forceinline__ void sp_reserve_agprs() {
 __device__ __forceinline__ void sp_mfma(int n, const f16x8& a, const f16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(n * 4), "n"(n * 4 + 3));
 }
+__device__ __forceinline__ void sp_mfma32(int n, const f16x8& a, const f16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(n * 16), "n"(n * 16 + 15));
+}
+template <int MI>
+__device__ __forceinline__ void sp_mfma_mi(int n, const f16x8& a, const f16x8& b) {
+  if constexpr (MI == 16) sp_mfma(n, a, b); else sp_mfma32(n, a, b);
+}
 // MFMA results -> v_accvgpr_read need the XDL write-back wait states; the compiler cannot see the
 // dependency, so the epilogue opens with them explicitly (once per output tile).
 __device__ __forceinline__ void sp_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15"); }
@@ -97,7 +117,7 @@ __device__ __forceinline__ void sp_zero_acc(int n) {
 // Slot plan of one K-step (see the header comment).
 template <class CFG>
 struct SpPlan {
-  static constexpr int FM = CFG::FM, FN = CFG::FN, T = FM * FN;
+  static constexpr int FM = CFG::NFA, FN = CFG::NFB, T = CFG::T;   // fragment reads per operand, MFMA slots
   static constexpr int NJA = CFG::NI_A / CFG::NW;            // A pieces per wave per tile
   static constexpr int NJB = CFG::NJ - NJA;                  // B pieces per wave per tile
   static constexpr int RS = 2;                               // one fragment read every RS MFMA slots
@@ -137,54 +157,56 @@ __device__ __forceinline__ void sp_sync() {
 // of the slot plan between them.  ONE body for all cases: two instantiations behind an if/else make
 // hipcc shuffle all 256 accumulators.
 template <class CFG, int PHASE>
-__device__ __forceinline__ void sp_interval(const f16x8 (&af)[CFG::FM],
-                                            const f16x8 (&bf)[CFG::FN], f16x8 (&naf)[CFG::FM],
-                                            f16x8 (&nbf)[CFG::FN], const char* next_a, const char* next_b,
+__device__ __forceinline__ void sp_interval(const f16x8 (&af)[CFG::NFA],
+                                            const f16x8 (&bf)[CFG::NFB], f16x8 (&naf)[CFG::NFA],
+                                            f16x8 (&nbf)[CFG::NFB], const char* next_a0, const char* next_a1,
+                                            const char* next_b0, const char* next_b1,
                                             __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
                                             const uint32_t (&voff)[CFG::NJ], int wave, char* stage2, uint32_t kbyte2) {
   using P = SpPlan<CFG>;
-  constexpr int FM = CFG::FM, FN = CFG::FN, T = FM * FN;
+  constexpr int FM = CFG::FM, FN = CFG::FN, NFA = CFG::NFA, NFB = CFG::NFB, T = CFG::T, MI = CFG::MI;
+  constexpr int RS = P::RS;
+  // fragment read r of an operand: sub-slice u = r / F, row block r % F
+  auto read_a = [&](int r) { return *(const f16x8*)((r / FM ? next_a1 : next_a0) + (r % FM) * MI * ROW_BYTES); };
+  auto read_b = [&](int r) { return *(const f16x8*)((r / FN ? next_b1 : next_b0) + (r % FN) * MI * ROW_BYTES); };
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = i * FN + j;
-      if (PHASE == 0 && n == P::X1) {                       // X1: the slice-1 A-fragment reads of tile t are retired
-        // LDS returns in order: only the B-fragment reads issued since may still be outstanding
-        constexpr int YOUNGER = (P::X1 + P::RS - 1) / P::RS - FM;
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(YOUNGER > 0 ? YOUNGER : 0) : "memory");
-        sp_sync();
-      }
-      if (PHASE == 1 && n == P::Y2) {                       // Y2: B pieces of tile t+1 have landed
-        wait_vmcnt<P::NJA + P::NB1>();
-        sp_sync();
-      }
-      sp_mfma(n, bf[j], af[i]);
-      // fragment reads of the next slice, one every RS slots so the four waves (which leave every
-      // sync point together) do not saturate the LDS pipe (unconditional: behind the last tile they
-      // read stale LDS, which is never used)
-      constexpr int RS = P::RS;
-      if (n % RS == 0) {
-        const int r = n / RS;
-        if (PHASE == 0) {
-          if (r < FM) naf[r] = *(const f16x8*)(next_a + r * 16 * ROW_BYTES);
-          else if (r < FM + FN) nbf[r - FM] = *(const f16x8*)(next_b + (r - FM) * 16 * ROW_BYTES);
-        } else {
-          if (r < FM) naf[r] = *(const f16x8*)(next_a + r * 16 * ROW_BYTES);
-          else if (n >= P::Y2 && (n - P::Y2) / RS < FN) nbf[(n - P::Y2) / RS] = *(const f16x8*)(next_b + ((n - P::Y2) / RS) * 16 * ROW_BYTES);
-        }
-      }
-      // LDS-DMA pieces of tile t+2 into the stage tile t is vacating.  Branch-free: behind the last
-      // tile kbyte2 is clamped to the last valid K offset, so the redundant pieces read valid memory
-      // and land in a stage nobody reads again (one wave per SIMD: a branch per piece costs MFMA issue)
+  for (int n = 0; n < T; ++n) {
+    const int u = n / (FM * FN), i = (n / FN) % FM, j = n % FN;   // k-slice, accumulator tile (i, j)
+    if (PHASE == 0 && n == P::X1) {                       // X1: the slice-1 A-fragment reads of tile t are retired
+      // LDS returns in order: only the B-fragment reads issued since may still be outstanding
+      constexpr int YOUNGER = (P::X1 + RS - 1) / RS - NFA;
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(YOUNGER > 0 ? YOUNGER : 0) : "memory");
+      sp_sync();
+    }
+    if (PHASE == 1 && n == P::Y2) {                       // Y2: B pieces of tile t+1 have landed
+      wait_vmcnt<P::NJA + P::NB1>();
+      sp_sync();
+    }
+    sp_mfma_mi<MI>(i * FN + j, bf[u * FN + j], af[u * FM + i]);
+    // fragment reads of the next interval, one every RS slots so the four waves (which leave every
+    // sync point together) do not saturate the LDS pipe (unconditional: behind the last tile they
+    // read stale LDS, which is never used)
+    if (n % RS == 0) {
+      const int r = n / RS;
       if (PHASE == 0) {
-        const int a = P::a_at(n);
-        if (a >= 0) sp_issue_piece<CFG>(rsA, voff, stage2, wave, a, kbyte2);
+        if (r < NFA) naf[r] = read_a(r);
+        else if (r < NFA + NFB) nbf[r - NFA] = read_b(r - NFA);
       } else {
-        const int b = P::b_at(n);
-        if (b >= 0) sp_issue_piece<CFG>(rsB, voff, stage2, wave, P::NJA + b, kbyte2);
+        if (r < NFA) naf[r] = read_a(r);
+        else if (n >= P::Y2 && (n - P::Y2) / RS < NFB) nbf[(n - P::Y2) / RS] = read_b((n - P::Y2) / RS);
       }
     }
+    // LDS-DMA pieces of tile t+2 into the stage tile t is vacating.  Branch-free: behind the last
+    // tile kbyte2 is clamped to the last valid K offset, so the redundant pieces read valid memory
+    // and land in a stage nobody reads again (one wave per SIMD: a branch per piece costs MFMA issue)
+    if (PHASE == 0) {
+      const int a = P::a_at(n);
+      if (a >= 0) sp_issue_piece<CFG>(rsA, voff, stage2, wave, a, kbyte2);
+    } else {
+      const int b = P::b_at(n);
+      if (b >= 0) sp_issue_piece<CFG>(rsB, voff, stage2, wave, P::NJA + b, kbyte2);
+    }
+  }
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
@@ -234,28 +256,77 @@ __device__ __forceinline__ void sp_interval(const f16x8 (&af)[CFG::FM],
   do {                                                                                                         \
     char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                          \
     char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                    \
-    /* interval A: MFMAs on slice 0 (set A); slice 1 of this step streams into set B */                        \
-    sp_interval<CFG, 0>(afA, bfA, afB, bfB, st + a_base_off + off1, st + b_base_off + off1, rsA, rsB,     \
-                        voff, wave, st, iss_kbyte);                                                            \
+    /* interval A: MFMAs on k 0..31 (set A); k 32..63 of this step streams into set B */                       \
+    sp_interval<CFG, 0>(afA, bfA, afB, bfB, st + a_base_off + off10, st + a_base_off + off11,                  \
+                        st + b_base_off + off10, st + b_base_off + off11, rsA, rsB, voff, wave, st, iss_kbyte); \
     /* Y1: my A pieces of step+1 have landed; its B pieces and the A pieces of step+2 may fly on.  The       \
        count is the number of YOUNGER LOADS only: loads retire in order among themselves, so it stays a      \
-       safe (merely conservative) bound while an epilogue's stores are still in the VM queue. */               \
+       safe (merely conservative) bound while an epilogue's stores are still in the VM queue.  Y1 also       \
+       frees the B region of this stage for the B pieces issued in interval B, so every wave's fragment      \
+       reads of it must have RETURNED (lgkmcnt), not merely been issued, before the barrier. */                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
     wait_vmcnt<P::NJB + P::NJA>();                                                                             \
     sp_sync();                                                                                                 \
-    /* interval B: MFMAs on slice 1 (set B); slice 0 of step+1 streams into set A */                           \
-    sp_interval<CFG, 1>(afB, bfB, afA, bfA, nst + a_base_off + off0, nst + b_base_off + off0, rsA, rsB,   \
-                        voff, wave, st, iss_kbyte);                                                            \
+    /* interval B: MFMAs on k 32..63 (set B); k 0..31 of step+1 streams into set A */                          \
+    sp_interval<CFG, 1>(afB, bfB, afA, bfA, nst + a_base_off + off00, nst + a_base_off + off01,                \
+                        nst + b_base_off + off00, nst + b_base_off + off01, rsA, rsB, voff, wave, st, iss_kbyte); \
     ++step;                                                                                                    \
   } while (0)
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- epilogue pieces.  A "unit" is what is live in VGPRs at once: one fragment row (MI = 16: FN tiles x 4
+// registers) or one 32x32 tile (MI = 32: 16 registers).  Quad x = tile * NQ + q lives in a[4x .. 4x+3]. -----
+// fp16 store of one 32x32 accumulator tile (operands swapped: lane holds C[m = lane & 31][n = 8q + 4(lane >> 5) + e],
+// register 4q + e).  WIDE: v_permlane32_swap pairs quads (q, q+1) so every lane owns 8 consecutive N = one
+// 16-byte store (cdna_hip_programming.md T21); otherwise four 8-byte stores.
+template <int WIDE>
+__device__ __forceinline__ void sp_store_tile32(const GemmArgs& g, int m, int nb, int lane, const f32x4 (&qd)[4]) {
+  const bool wide = (WIDE == 1) || (WIDE < 0 && ((g.N & 7) == 0) && ((g.ldc & 7) == 0) &&
+                                    ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0));
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  if (wide) {
+#pragma unroll
+    for (int qp = 0; qp < 4; qp += 2) {
+      const h2 a01 = {(f16)qd[qp][0], (f16)qd[qp][1]}, a23 = {(f16)qd[qp][2], (f16)qd[qp][3]};
+      const h2 b01 = {(f16)qd[qp + 1][0], (f16)qd[qp + 1][1]}, b23 = {(f16)qd[qp + 1][2], (f16)qd[qp + 1][3]};
+      // lanes 32-63 of the first operand <-> lanes 0-31 of the second: lower lanes end up with quad qp of
+      // both halves (n = 8qp .. 8qp+7), upper lanes with quad qp+1 of both halves (n = 8(qp+1) .. +7)
+      const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, b01), false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a23), __builtin_bit_cast(unsigned, b23), false, false);
+      const int n = nb + 8 * (qp + (lane >> 5));
+      if (m < g.M && n < g.N) {
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+        const u4 o = {r0[0], r1[0], r0[1], r1[1]};
+        HGEMM_STORE_C((u4*)(g.C + (size_t)m * g.ldc + n), o);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nb + 8 * q + 4 * (lane >> 5);
+      if (m < g.M && n < g.N) {
+        const f16x4 o = {(f16)qd[q][0], (f16)qd[q][1], (f16)qd[q][2], (f16)qd[q][3]};
+        HGEMM_STORE_C((f16x4*)(g.C + (size_t)m * g.ldc + n), o);
+      }
+    }
+  }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
 // EPI: 0 = narrow fp16 epilogue, 1 = wide fp16 epilogue (host checked N % 8, ldc % 8, 16-B aligned C),
-//      2 = fp32 split-K partials
+//      2 = fp32 split-K partials for the two-pass combine / the hybrid tail, 3 = single-launch (fused) split-K
+constexpr int SP_EPI_NARROW = 0, SP_EPI_WIDE = 1, SP_EPI_SLAB = 2, SP_EPI_FUSED = 3;
+
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ;
+  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ, MI = CFG::MI;
+  constexpr int NFA = CFG::NFA, NFB = CFG::NFB;
+  constexpr int NQ = CFG::ACC / 4;              // f32x4 quads per accumulator tile
 
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
+  // the two stages + one word for the fused split-K vote (ONE LDS object: a second one makes hipcc drain
+  // vmcnt in front of every ds_read of the pipeline)
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -267,10 +338,11 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   const ItemWalk walk = persistent_walk(g.items);
   if (walk.count == 0) return;
 
-  // fragment offsets of the two K=32 slices inside a stage (same image as hgemm_tn_kernel)
-  const int l15 = lane & 15, lq = lane >> 4, sw = l15 >> 1;
-  const int off0 = l15 * ROW_BYTES + (((0 * 4 + lq) ^ sw) << 4);
-  const int off1 = l15 * ROW_BYTES + (((1 * 4 + lq) ^ sw) << 4);
+  // fragment offsets inside a stage (same image as hgemm_tn_kernel): interval h (K half), sub-slice u
+  //   MI = 16: row lane & 15, 16-B chunk 4h + (lane >> 4);  MI = 32: row lane & 31, chunk 4h + 2u + (lane >> 5)
+  const int lr = lane & (MI - 1), lq = lane / MI, sw = (lr >> 1) & 7;
+  auto frag_off = [&](int h, int u) { return lr * ROW_BYTES + (((4 * h + 2 * u + lq) ^ sw) << 4); };
+  const int off00 = frag_off(0, 0), off01 = frag_off(0, 1), off10 = frag_off(1, 0), off11 = frag_off(1, 1);
   const int a_base_off = wave_m * CFG::TM * ROW_BYTES;
   const int b_base_off = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
 
@@ -292,15 +364,17 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
   // the accumulators are cleared behind the prologue's DMA issue, in the shadow of its HBM latency
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
+  for (int x = 0; x < FM * FN * NQ; ++x) sp_zero_acc(x);
   wait_vmcnt<NJ>();
   __builtin_amdgcn_s_barrier();
 
-  f16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
+  f16x8 afA[NFA], bfA[NFB], afB[NFA], bfB[NFB];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) afA[i] = *(const f16x8*)(smem + a_base_off + off0 + i * 16 * ROW_BYTES);
+  for (int r = 0; r < NFA; ++r)
+    afA[r] = *(const f16x8*)(smem + a_base_off + (r / FM ? off01 : off00) + (r % FM) * MI * ROW_BYTES);
 #pragma unroll
-  for (int j = 0; j < FN; ++j) bfA[j] = *(const f16x8*)(smem + b_base_off + off0 + j * 16 * ROW_BYTES);
+  for (int r = 0; r < NFB; ++r)
+    bfA[r] = *(const f16x8*)(smem + b_base_off + (r / FN ? off01 : off00) + (r % FN) * MI * ROW_BYTES);
 
   int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
 #pragma clang loop unroll(disable)
@@ -322,24 +396,98 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
       SP_K_STEP();
       SP_ISSUE_ADVANCE();
     }
-    // ---- epilogue of this work item; the next item's first two K-steps are already in flight.  Row by
-    //      row: read 4*FN accumulators, convert, store, re-zero -- one fragment row live in VGPRs ----------
+    // ---- epilogue of this work item; the next item's first two K-steps are already in flight.  Unit by
+    //      unit: read the accumulators, re-zero them, convert, store -- one unit live in VGPRs ----------
     sp_mfma_drain();
-    const bool skip_store = (g.debug & 2) != 0;
+    const bool rezero = item + 1 < walk.count;   // (the last tile's accumulators are not needed again)
+    const int m_wave = tc.m0 + wave_m * CFG::TM, n_wave = tc.n0 + wave_n * CFG::TN;
+    float* const my_slab = (EPI == SP_EPI_FUSED) ? g.partial + (size_t)tc.item * ((size_t)BM * BN) : nullptr;
+    (void)m_wave; (void)n_wave; (void)my_slab;
+    if constexpr (MI == 16) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 row[FN];
+      for (int i = 0; i < FM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 row[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
-      if (item + 1 < walk.count) {  // (the last tile's accumulators are not needed again)
+        for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
+        if (rezero) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+          for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+        }
+        if constexpr (EPI == SP_EPI_FUSED) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) *(f32x4*)fused_slot<CFG::THREADS>(my_slab, i * FN + j, tid) = row[j];
+        } else {
+          if (!HGEMM_DBG(g, 2))
+            store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+        }
       }
-      if (!skip_store)
-        store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == 2, EPI == 2 ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+    } else {
+#pragma unroll
+      for (int x = 0; x < FM * FN; ++x) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int i = x / FN, j = x % FN;
+        f32x4 qd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qd[q] = sp_read_acc(x * 4 + q);
+        if (rezero) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sp_zero_acc(x * 4 + q);
+        }
+        if constexpr (EPI == SP_EPI_FUSED) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4*)fused_slot<CFG::THREADS>(my_slab, x * 4 + q, tid) = qd[q];
+        } else if constexpr (EPI == SP_EPI_SLAB) {
+          const int m = m_wave + i * 32 + (lane & 31);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n_wave + j * 32 + 8 * q + 4 * (lane >> 5);
+            if (m < g.M && n < g.N) *(f32x4*)(tc.slab + (size_t)(m - tc.m0) * tc.slab_ld + (n - tc.n0)) = qd[q];
+          }
+        } else {
+          if (!HGEMM_DBG(g, 2)) sp_store_tile32<EPI>(g, m_wave + i * 32 + (lane & 31), n_wave + j * 32, lane, qd);
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (EPI == SP_EPI_FUSED) {
+      // single-launch split-K: publish my slab, draw a ticket; the last arriver of this tile adds the slabs
+      // in split order and writes the fp16 tile (accumulators are not involved: they belong to the next item)
+      if (fused_publish_and_vote(g, tc.tile, (volatile unsigned*)(smem + CFG::FLAG_OFF), tid)) {
+        const size_t slab_elems = (size_t)BM * BN;
+        const size_t stride = (size_t)g.tiles_m * g.tiles_n * slab_elems;
+        float* base = g.partial + (size_t)tc.tile * slab_elems;
+        if constexpr (MI == 16) {
+#pragma unroll 1
+          for (int i = 0; i < FM; ++i) {
+            f32x4 row[FN];
+            for (int sidx = 0; sidx < g.splits; ++sidx) {
+#pragma unroll
+              for (int j = 0; j < FN; ++j) {
+                const f32x4 v = *(const f32x4*)fused_slot<CFG::THREADS>(base + (size_t)sidx * stride, i * FN + j, tid);
+                row[j] = (sidx == 0) ? v : row[j] + v;
+              }
+            }
+            store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
+          }
+        } else {
+#pragma unroll 1
+          for (int x = 0; x < FM * FN; ++x) {
+            const int i = x / FN, j = x % FN;
+            f32x4 qd[4];
+            for (int sidx = 0; sidx < g.splits; ++sidx) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4*)fused_slot<CFG::THREADS>(base + (size_t)sidx * stride, x * 4 + q, tid);
+                qd[q] = (sidx == 0) ? v : qd[q] + v;
+              }
+            }
+            sp_store_tile32<-1>(g, m_wave + i * 32 + (lane & 31), n_wave + j * 32, lane, qd);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   wait_vmcnt<0>();  // redundant tail pieces must not outlive the workgroup's LDS allocation
 #endif  // __HIP_DEVICE_COMPILE__

@@ -1,71 +1,69 @@
 // Host-side launch thunks for the kernel instantiations listed in hgemm_configs.def.
 #pragma once
-#include "hgemm_kernel_pp.hpp"
 #include "hgemm_kernel_sp.hpp"
 
 #include <hip/hip_ext.h>
 
 namespace hgemm_mi355x {
 
-// One thunk per geometry; `splitk` selects the fp32-slab epilogue.  No per-call attribute
-// setting, allocation or synchronisation happens here (the reference calls
+// One thunk per geometry; `epi` selects the epilogue (EPI_C16 / EPI_SLAB / EPI_FUSED).  No per-call
+// attribute setting, allocation or synchronisation happens here (the reference calls
 // cudaFuncSetAttribute on every invocation, kernels/a100_F32F16F16F32/64_4096_64.cu:256-261).
-// One-shot timing hook (hgemm_mi355x_time_next_launch): when armed, the next main-kernel dispatch of
-// this thread carries the two events on its own AQL packet (hipExtLaunchKernelGGL), so their distance
-// is the kernel's execution time as the profiler sees it -- no marker packets between kernels.
+//
+// Timing hook (hgemm_mi355x_time_next_launch): when armed, the FIRST dispatch of the next GEMM call of this
+// thread carries the start event and its LAST dispatch (the main kernel, or the combine kernel of a
+// two-pass / hybrid plan) the stop event, both on the dispatches' own AQL packets
+// (hipExtLaunchKernelGGL): their distance is the plan's device time as the profiler sees it, with no
+// marker packets between kernels.
 struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; };
 extern thread_local LaunchTiming t_launch_timing;
 
-#define HGEMM_LAUNCH(KERNEL, GRID, THREADS, STREAM, ARGS)                                                   \
+// which of the armed events this dispatch carries
+struct TimingSlot { hipEvent_t start = nullptr, stop = nullptr; };
+inline TimingSlot timing_slot(bool first, bool last) {
+  TimingSlot s;
+  if (first) { s.start = t_launch_timing.start; t_launch_timing.start = nullptr; }
+  if (last) { s.stop = t_launch_timing.stop; t_launch_timing.stop = nullptr; }
+  return s;
+}
+
+#define HGEMM_LAUNCH(KERNEL, GRID, THREADS, STREAM, SLOT, ...)                                              \
   do {                                                                                                      \
-    if (t_launch_timing.start) {                                                                            \
-      hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(THREADS), 0, STREAM, t_launch_timing.start,            \
-                            t_launch_timing.stop, 0, ARGS);                                                 \
-      t_launch_timing = LaunchTiming{};                                                                     \
-    } else {                                                                                                \
-      hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(THREADS), 0, STREAM, ARGS);                               \
-    }                                                                                                       \
+    if ((SLOT).start || (SLOT).stop)                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(THREADS), 0, STREAM, (SLOT).start, (SLOT).stop, 0,     \
+                            __VA_ARGS__);                                                                   \
+    else                                                                                                    \
+      hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(THREADS), 0, STREAM, __VA_ARGS__);                        \
   } while (0)
 
 template <class CFG>
-void launch_cfg(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
-  if (splitk)
-    HGEMM_LAUNCH((hgemm_tn_kernel<CFG, true>), grid, CFG::THREADS, stream, g);
+void launch_cfg(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_kernel<CFG, EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
+    HGEMM_LAUNCH((hgemm_tn_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
   else
-    HGEMM_LAUNCH((hgemm_tn_kernel<CFG, false>), grid, CFG::THREADS, stream, g);
+    HGEMM_LAUNCH((hgemm_tn_kernel<CFG, EPI_C16>), grid, CFG::THREADS, stream, ts, g);
 }
 
 template <class CFG>
-void launch_pp(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
-  if constexpr (CFG::MODE == 0) {
-    if (splitk)
-      HGEMM_LAUNCH((hgemm_tn_pp_kernel<CFG, true>), grid, CFG::THREADS, stream, g);
-    else
-      HGEMM_LAUNCH((hgemm_tn_pp_kernel<CFG, false>), grid, CFG::THREADS, stream, g);
-  } else {
-    if (splitk)
-      HGEMM_LAUNCH((hgemm_tn_cp_kernel<CFG, true>), grid, CFG::THREADS, stream, g);
-    else
-      HGEMM_LAUNCH((hgemm_tn_cp_kernel<CFG, false>), grid, CFG::THREADS, stream, g);
-  }
-}
-
-template <class CFG>
-void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, bool splitk) {
+void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
   const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-  if (splitk)
-    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, 2>), grid, CFG::THREADS, stream, g);
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, SP_EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
+    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, SP_EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
   else if (wide)
-    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, 1>), grid, CFG::THREADS, stream, g);
+    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
   else
-    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, 0>), grid, CFG::THREADS, stream, g);
+    HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
 }
 
 struct KernelEntry {
   const char* name;
   int bm, bn, wm, wn, mi, nbuf;
   int threads, lds_bytes;
-  void (*launch)(const GemmArgs&, int, hipStream_t, bool);
+  void (*launch)(const GemmArgs&, int, hipStream_t, int, TimingSlot);
   int persistent_wgs;  // > 0: the kernel walks its work items itself, launch at most this many workgroups
 };
 
@@ -73,9 +71,12 @@ extern const KernelEntry g_kernel_table[];
 extern const int g_num_kernels;
 
 void launch_splitk_reduce(const float* partial, f16* C, int M, int N, int ldc, int splits,
-                          hipStream_t stream);
-void launch_tail_reduce(const GemmArgs& g, int BM, int BN, hipStream_t stream);
+                          hipStream_t stream, TimingSlot ts);
+void launch_tail_reduce(const GemmArgs& g, int BM, int BN, hipStream_t stream, TimingSlot ts);
+// Any-shape kernels (hgemm_kernel_rg.hpp): MFMA with register staging for ragged K / N / unaligned views,
+// and the one-output-per-thread reference kernel (config id -1).
+void launch_ragged(const GemmArgs& g, hipStream_t stream, TimingSlot ts);
 void launch_generic(const f16* A, const f16* B, f16* C, int M, int N, int K, int lda, int ldb,
-                    int ldc, hipStream_t stream);
+                    int ldc, hipStream_t stream, TimingSlot ts);
 
 }  // namespace hgemm_mi355x

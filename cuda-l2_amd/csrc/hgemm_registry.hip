@@ -1,17 +1,17 @@
 // Kernel registry (config id -> launch thunk) and the two helper kernels' launchers.
 #include "hgemm_launch.hpp"
+#include "hgemm_kernel_rg.hpp"
+
+#include <algorithm>
 
 namespace hgemm_mi355x {
 
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB) \
-  extern template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, bool);
-#define HGEMM_PP(G, BM, BN, WM, WN, MODE) \
-  extern template void launch_pp<CfgPP<BM, BN, WM, WN, MODE>>(const GemmArgs&, int, hipStream_t, bool);
-#define HGEMM_SP(G, BM, BN, WM, WN) \
-  extern template void launch_sp<CfgSP<BM, BN, WM, WN>>(const GemmArgs&, int, hipStream_t, bool);
+  extern template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_SP(G, BM, BN, WM, WN, MI) \
+  extern template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
-#undef HGEMM_PP
 #undef HGEMM_SP
 
 // The table holds host function pointers: keep it out of the device pass.
@@ -24,33 +24,22 @@ thread_local LaunchTiming t_launch_timing;
    "_s" HGEMM_STR(NB),                                                                         \
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
    Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0},
-#define HGEMM_PP(G, BM, BN, WM, WN, MODE)
-#define HGEMM_SP(G, BM, BN, WM, WN)
+#define HGEMM_SP(G, BM, BN, WM, WN, MI)
 const KernelEntry g_kernel_table[] = {
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
-#undef HGEMM_PP
-#undef HGEMM_SP
-#define HGEMM_SP(G, BM, BN, WM, WN)
-#define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
-#define HGEMM_PP(G, BM, BN, WM, WN, MODE)                                                        \
-  {"p" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_v" HGEMM_STR(MODE), BM, \
-   BN, WM, WN, 16, 4, CfgPP<BM, BN, WM, WN, MODE>::THREADS, CfgPP<BM, BN, WM, WN, MODE>::LDS_BYTES,  \
-   &launch_pp<CfgPP<BM, BN, WM, WN, MODE>>, 0},
-#include "hgemm_configs.def"
-#undef HGEMM_CFG
-#undef HGEMM_PP
 #undef HGEMM_SP
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
-#define HGEMM_PP(G, BM, BN, WM, WN, MODE)
-#define HGEMM_SP(G, BM, BN, WM, WN)                                                             \
-  {"s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN), BM, BN, WM, WN, 16, 2, \
-   CfgSP<BM, BN, WM, WN>::THREADS, CfgSP<BM, BN, WM, WN>::LDS_BYTES, &launch_sp<CfgSP<BM, BN, WM, WN>>,      \
-   256 * (160 * 1024 / CfgSP<BM, BN, WM, WN>::LDS_BYTES)},
+// MI = 16 members keep their round-1 names (tuned tables refer to plans by name); MI = 32 members add "_m32"
+#define HGEMM_SP_NAME_16(BM, BN, WM, WN) "s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
+#define HGEMM_SP_NAME_32(BM, BN, WM, WN) "s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m32"
+#define HGEMM_SP(G, BM, BN, WM, WN, MI)                                                          \
+  {HGEMM_SP_NAME_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2,                                      \
+   CfgSP<BM, BN, WM, WN, MI>::THREADS, CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64,                  \
+   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64))},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG
-#undef HGEMM_PP
 #undef HGEMM_SP
 const int g_num_kernels = (int)(sizeof(g_kernel_table) / sizeof(g_kernel_table[0]));
 #endif  // !__HIP_DEVICE_COMPILE__
@@ -115,34 +104,57 @@ __global__ void __launch_bounds__(256) hgemm_generic_kernel(const f16* __restric
                                                             f16* __restrict__ C, int M, int N, int K,
                                                             int lda, int ldb_rowmajor, int ldc) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (m >= M || n >= N) return;
-  float s = 0.f;
-  for (int k = 0; k < K; ++k) s = fmaf((float)A[(size_t)m * lda + k], (float)B[(size_t)k * ldb_rowmajor + n], s);
-  C[(size_t)m * ldc + n] = (f16)s;
+  if (n >= N) return;
+  // grid-stride over M: gridDim.y is capped at 65535 (M > 262140 used to fail the launch)
+  for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < M; m += gridDim.y * 4) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf((float)A[(size_t)m * lda + k], (float)B[(size_t)k * ldb_rowmajor + n], s);
+    C[(size_t)m * ldc + n] = (f16)s;
+  }
 }
 
 void launch_splitk_reduce(const float* partial, f16* C, int M, int N, int ldc, int splits,
-                          hipStream_t stream) {
+                          hipStream_t stream, TimingSlot ts) {
   const size_t quads = ((size_t)M * N) >> 2;
   // small outputs: 64-thread blocks so the (latency-bound) slab reads spread over more CUs
   const int threads = quads <= 64 * 1024 ? 64 : 256;
   int grid = (int)((quads + threads - 1) / threads);
   if (grid > 256 * 8) grid = 256 * 8;  // grid-stride beyond 8 blocks per CU
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(hgemm_splitk_reduce_kernel, dim3(grid), dim3(threads), 0, stream, partial, C, M, N,
-                     ldc, splits);
+  HGEMM_LAUNCH(hgemm_splitk_reduce_kernel, grid, threads, stream, ts, partial, C, M, N, ldc, splits);
 }
 
-void launch_tail_reduce(const GemmArgs& g, int BM, int BN, hipStream_t stream) {
-  hipLaunchKernelGGL(hgemm_tail_reduce_kernel, dim3(g.tail_tiles * (BM / 16)), dim3(256), 0, stream, g, BM, BN);
+void launch_tail_reduce(const GemmArgs& g, int BM, int BN, hipStream_t stream, TimingSlot ts) {
+  HGEMM_LAUNCH(hgemm_tail_reduce_kernel, g.tail_tiles * (BM / 16), 256, stream, ts, g, BM, BN);
+}
+
+// largest power of two <= 8 (halfs) that divides the row stride, K and the pointer's alignment
+static int piece_width(const void* p, int ld, int K) {
+  int w = 8;
+  while (w > 1 && ((ld % w) || (K % w) || (reinterpret_cast<uintptr_t>(p) % (2 * w)))) w >>= 1;
+  return w;
+}
+
+void launch_ragged(const GemmArgs& g0, hipStream_t stream, TimingSlot ts) {
+  GemmArgs g = g0;
+  const int wa = piece_width(g.A, g.lda, g.K), wb = piece_width(g.Bt, g.ldb, g.K);
+  const int vec_c = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0);
+  using Small = Cfg<64, 64, 2, 2, 16, 2>;
+  using Big = Cfg<128, 128, 2, 2, 16, 2>;
+  const long tiles_big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if (tiles_big >= 256) {
+    g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
+    HGEMM_LAUNCH((hgemm_tn_ragged_kernel<Big>), g.tiles_m * g.tiles_n, Big::THREADS, stream, ts, g, wa, wb, vec_c);
+  } else {
+    g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 63) / 64;
+    HGEMM_LAUNCH((hgemm_tn_ragged_kernel<Small>), g.tiles_m * g.tiles_n, Small::THREADS, stream, ts, g, wa, wb, vec_c);
+  }
 }
 
 void launch_generic(const f16* A, const f16* B, f16* C, int M, int N, int K, int lda, int ldb,
-                    int ldc, hipStream_t stream) {
-  dim3 grid((N + 63) / 64, (M + 3) / 4);
-  hipLaunchKernelGGL(hgemm_generic_kernel, grid, dim3(256), 0, stream, A, B, C, M, N, K, lda, ldb,
-                     ldc);
+                    int ldc, hipStream_t stream, TimingSlot ts) {
+  dim3 grid((N + 63) / 64, (unsigned)std::min<long>(((long)M + 3) / 4, 65535));
+  HGEMM_LAUNCH(hgemm_generic_kernel, grid, 256, stream, ts, A, B, C, M, N, K, lda, ldb, ldc);
 }
 
 }  // namespace hgemm_mi355x

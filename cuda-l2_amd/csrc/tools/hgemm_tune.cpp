@@ -25,6 +25,10 @@
 
 #include "../../../include/hgemm_mi355x.h"
 
+// Ablation switches exist only in the -DHGEMM_ABLATION build of the library (build.py: HGEMM_LIB_SUFFIX=ablation
+// HGEMM_EXTRA_HIPFLAGS=-DHGEMM_ABLATION); against the shipping library the symbol is absent and --debug refuses.
+extern "C" int hgemm_mi355x_set_debug(int flags) __attribute__((weak));
+
 #define HIP_OK(x)                                                                         \
   do {                                                                                    \
     hipError_t e_ = (x);                                                                  \
@@ -404,7 +408,10 @@ int main(int argc, char** argv) {
     else if (a == "--reps") reps = atoi(next());
     else if (a == "--lib") use_lib = true;
     else if (a == "--ld") g_ld_override = atoi(next());
-    else if (a == "--debug") hgemm_mi355x_set_debug(atoi(next()));
+    else if (a == "--debug") {
+      if (!hgemm_mi355x_set_debug) { fprintf(stderr, "--debug needs the ablation build of the library (lib_ablation/)\n"); return 2; }
+      hgemm_mi355x_set_debug(atoi(next()));
+    }
     else if (a == "--fill") g_zero_fill = (std::string(next()) == "zero");
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }

@@ -47,13 +47,28 @@ typedef enum {
  * selects the compute type exactly as the reference's cublas/fp16 vs cublas/fp32 trees do. */
 typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
 
+/* Special config ids of hgemm_mi355x_launch / hgemm_mi355x_plan (ids >= 0 index the geometry table). */
+#define HGEMM_CONFIG_GENERIC (-1) /* one-output-per-thread reference kernel; reads b (row-major)        */
+#define HGEMM_CONFIG_RAGGED  (-2) /* register-staged MFMA kernel for any M,N,K / alignment; reads b_col_major */
+
+/* Split-K forms.  `splits` > 1 selects the single-launch form (fp32 partials + per-tile arrival counter, the
+ * last workgroup to arrive adds the partials in split order and writes the tile -- replaces the reference's
+ * atomicAdd split-K, kernels/a100_F32F16F16F32/64_256_16384.cu:149-152); OR-ing HGEMM_SPLITK_TWO_PASS into
+ * `splits` selects the two-launch form (fp32 slabs [splits][M][N] + a combine kernel).  Both are
+ * deterministic (fixed summation order). */
+#define HGEMM_SPLITK_TWO_PASS 0x10000
+#define HGEMM_SPLITK_MASK     0x0ffff
+
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)
  * (reference kernels/a100_F32F16F16F32/64_4096_64.cu:275-287) and cuda_l2_<dev>_fp16
  * (kernels/a100_F16F16F16F16/4096_4096_4096.cu:280-295).  Picks the tuned kernel geometry /
  * split-K plan for (M,N,K) (tuned table first, analytic model otherwise) and launches it.
- * Any M,N,K >= 1 is accepted; shapes the MFMA path cannot take (K % 64 != 0, N % 4 != 0,
- * pointers not 16-byte aligned) run on a slow generic kernel. */
+ * Any M,N,K >= 1 is accepted; shapes the LDS-DMA kernels cannot take (K % 64 != 0, N % 4 != 0,
+ * pointers or strides not 16-byte aligned, operands beyond 32-bit tile offsets) run on a register-staged
+ * MFMA kernel that pads on the way into LDS (the reference pads in the harness, tools/utils.py:8-36).
+ * Thread / stream safety: calls may be issued from any thread on any stream and device; split-K plans use
+ * a library-owned workspace that is private to the (device, stream) pair of the call. */
 int hgemm_mi355x_fp32(const void* a, const void* b, const void* b_col_major, void* c,
                       int M, int N, int K, void* stream);
 int hgemm_mi355x_fp16(const void* a, const void* b, const void* b_col_major, void* c,
@@ -62,8 +77,11 @@ int hgemm_mi355x_fp16(const void* a, const void* b, const void* b_col_major, voi
 /* Explicit-plan launch: what a per-shape kernel file
  * (cuda-l2_amd/kernels/mi355x_<acc>/<M>_<N>_<K>.hip, the analogue of the reference's
  * kernels/<dev>_<acc>/<M>_<N>_<K>.cu) and the autotuner call.
- *   config_id  index into the geometry table (hgemm_mi355x_config_*), or -1 for the generic kernel
- *   splits     split-K factor >= 1 (fp32 slabs + deterministic combine kernel when > 1)
+ *   config_id  index into the geometry table (hgemm_mi355x_config_*), HGEMM_CONFIG_GENERIC or
+ *              HGEMM_CONFIG_RAGGED; a table geometry whose alignment rules the operands do not meet is
+ *              served by the ragged kernel
+ *   splits     split-K factor >= 1, optionally | HGEMM_SPLITK_TWO_PASS (see above); clamped to K / 64;
+ *              degrades to 1 when no workspace is available (lent buffer too small, out of memory)
  *   group_m    rasterisation group height in tiles (>= 1)
  * lda/ldb/ldc are row strides in elements (ldb is the row stride of b_col_major, i.e. >= K). */
 int hgemm_mi355x_launch(int config_id, int splits, int group_m,
@@ -87,17 +105,23 @@ const char* hgemm_mi355x_config_name(int config_id);
 int hgemm_mi355x_config_info(int config_id, int out[8]);
 int hgemm_mi355x_config_by_name(const char* name);
 
-/* Split-K workspace: by default the library grows a private device buffer on demand (first
- * use only, never in steady state).  A caller may instead lend its own buffer. */
+/* Split-K workspace.  Default: the library keeps one private device buffer per (device, stream) pair that
+ * issued a split-K plan and grows it on first use of a bigger plan only (never in steady state; growing
+ * frees the old buffer with hipFree, which synchronises the device).  Concurrent GEMMs on different streams
+ * or devices therefore never share partial sums.
+ * hgemm_mi355x_set_workspace lends ONE caller-owned buffer instead (NULL returns to the default): it is
+ * bound to the device that is current at the call, used for every stream of that device -- so the caller
+ * must not run split-K GEMMs concurrently on several streams while it is lent -- and its first 256 KiB are
+ * zeroed here (tile arrival counters).  A plan that does not fit the lent buffer runs with splits = 1.
+ * hgemm_mi355x_workspace_bytes gives a sufficient size for (M, N, splits); hgemm_mi355x_release_workspaces
+ * frees the library-owned buffers (call with no GEMM in flight). */
 int hgemm_mi355x_set_workspace(void* device_ptr, size_t bytes);
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits);
+int hgemm_mi355x_release_workspaces(void);
 
 const char* hgemm_mi355x_strerror(int status);
 int hgemm_mi355x_last_hip_error(void);
 const char* hgemm_mi355x_version(void);
-/* Ablation switches for the native tuner (bit 0: skip steady-state LDS-DMA -> wrong results,
- * timing only).  Returns the previous value.  Never set by the library itself. */
-int hgemm_mi355x_set_debug(int flags);
 
 /* ------------------------------------------------------------------------------------------
  * Vendor baselines (same tensors, same process, as in the reference's cublas/ tree).
@@ -129,6 +153,11 @@ int hgemm_hipblaslt_autotune_tn(const void* a, const void* b_col_major, void* c,
 /* Introspection for reports: candidates tried / median ms of the winner (nn = 0, tn = 1). */
 int hgemm_hipblaslt_autotune_candidates(int tn);
 double hgemm_hipblaslt_autotune_best_ms(int tn);
+/* 1 when the last hipBLASLt problem prepared with acc = HGEMM_ACC_FP16 for this layout found no
+ * HIPBLAS_COMPUTE_16F kernel and runs with 32F compute instead (result files report it as
+ * "hipblaslt_compute16_fallback"), 0 when 16F compute is in use or acc was FP32, -1 before any call.
+ * which: 0 = heuristic, 1 = autotune; tn: 0 = nn, 1 = tn. */
+int hgemm_hipblaslt_compute16_fallback(int which, int tn);
 
 /* Device helper used by the autotune baseline and the native tools: fill `n` fp16 values with
  * N(0,1) samples (counter-based generator; `seed` makes runs reproducible). */
@@ -138,8 +167,9 @@ int hgemm_fill_normal_f16(void* device_ptr, size_t n, unsigned long long seed, v
  * benchmarking_utils.py:23-31) ------------------------------------------------------------------
  * hgemm_mi355x_time_next_launch arms a one-shot hook: the next GEMM call of the calling thread puts
  * the two events on its main kernel's own dispatch packet, so hgemm_mi355x_event_elapsed_us returns
- * that kernel's execution time as rocprofv3 reports it (event-record marker packets around a launch
- * add ~6 us of queue gaps on MI355X).  For split-K plans the reduce kernel is not included.
+ * that plan's device time as rocprofv3 reports it (event-record marker packets around a launch
+ * add ~6 us of queue gaps on MI355X).  Plans with several kernels (two-pass split-K, hybrid tail) carry the
+ * start event on their first dispatch and the stop event on their last one, so the combine is included.
  * Pass (NULL, NULL) to disarm.  Events are created / destroyed with the two helpers below. */
 void* hgemm_mi355x_event_create(void);
 int hgemm_mi355x_event_destroy(void* event);
