@@ -147,7 +147,7 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   // geomean regret of the model's pick against the measured best 2.0 % (3.9 % before the fit).
   // MFMA efficiency falls with the wave tile's operand reuse (LDS bytes per flop); the software-
   // pipelined family ('s', one wave per SIMD) sustains ~1.5x the classic schedule's rate.
-  const char family = e.name[0];
+  const char family = e.name[0] == 'q' ? 's' : e.name[0];   // 'q' = 's' with the early-A split
   const double reuse = (double)tm * tn / (tm + tn);
   const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (family == 's' ? 1.47 : family == 'p' ? 1.12 : 1.0);
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
@@ -295,7 +295,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
   if (!a || !c || M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
   if (config_id >= g_num_kernels || config_id < HGEMM_CONFIG_RAGGED) return HGEMM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool two_pass = (splits_arg & HGEMM_SPLITK_TWO_PASS) != 0;
+  const bool want_fused = (splits_arg & HGEMM_SPLITK_FUSED) != 0;
   int splits = splits_arg & HGEMM_SPLITK_MASK;
 
   GemmArgs g;
@@ -334,12 +334,12 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     splits = (ksteps + steps_per_split - 1) / steps_per_split;  // no empty split
     g.group_m = std::max(1, std::min(group_m, g.tiles_m));
     if (tiles * splits > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
-    // Split-K: single-launch ("fused") by default, two-pass (slabs + combine kernel) on request or when the
-    // tile count exceeds the counter block.  No workspace (lent buffer too small, allocation failed) means
+    // Split-K: two-pass (slabs + combine kernel) by default; single-launch ("fused") on request, unless the
+    // tile count exceeds the counter block or the kernel family has no fused epilogue.  No workspace (lent buffer too small, allocation failed) means
     // no split-K: the plan degrades to splits = 1 instead of failing.
     int epi = EPI_C16;
     if (splits > 1) {
-      const bool fused = !two_pass && tiles <= (long)kMaxFusedTiles;
+      const bool fused = want_fused && tiles <= (long)kMaxFusedTiles && e.has_fused;
       const size_t slab_bytes = fused ? (size_t)tiles * splits * e.bm * e.bn * sizeof(float)
                                       : (size_t)splits * M * N * sizeof(float);
       unsigned* counters = nullptr;

@@ -18,7 +18,16 @@ namespace hgemm_mi355x {
 #define HGEMM_SPINST_3(BM, BN, WM, WN, MI) \
   template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_SP(G, BM, BN, WM, WN, MI) HGEMM_SPINST_##G(BM, BN, WM, WN, MI)
+#define HGEMM_SQINST_0(...)
+#define HGEMM_SQINST_1(...)
+#define HGEMM_SQINST_2(...)
+#define HGEMM_SQINST_3(...)
+#undef HGEMM_SQINST_3
+#define HGEMM_SQINST_3(BM, BN, WM, WN) \
+  template void launch_sq<CfgSQ<BM, BN, WM, WN>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_SQ(G, BM, BN, WM, WN) HGEMM_SQINST_##G(BM, BN, WM, WN)
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
+#undef HGEMM_SQ
 }  // namespace hgemm_mi355x

@@ -1,0 +1,311 @@
+// Family "q": the software-pipelined one-wave-per-SIMD kernel (hgemm_kernel_sp.hpp) with an EARLY-A
+// operand split: two barriers per K-step instead of three, and ~1.5x the LDS-DMA flight time.
+//
+// Why (round-2 measurements): family "s" and hipBLASLt's kernel of the same geometry execute
+// the same instruction counts; the 5-10 % gap on the compute-bound shapes is wave time parked at the sync
+// points (SQ_WAIT_ANY 8-11 % vs 4-10 %).  In "s" the A pieces of a tile fly for only 66-108 MFMA slots
+// (the A region of a stage is released late, after the slice-1 A fragments were read in interval A of the
+// step that consumes the stage), and a K-step has three barriers (X1, Y1, Y2).
+//
+// Here the A fragments of BOTH K=32 slices of tile t+1 are read one K-step early (during K-step t, into a
+// third fragment register set: +32 VGPRs), which frees the A region of its stage half a K-step earlier,
+// and every sync point pairs one "landed" wait with one "region free" wait:
+//
+//   K-step t, stage s = t & 1 (tile t in stage s, tile t+1 in stage s^1); T = FM*FN MFMA slots per interval
+//   interval A(t): MFMAs slice 0 = X x U
+//       [0, RS*FN)        ds_read B fragments slice 1 of tile t            -> V     (from B[s])
+//       P                 lgkmcnt(0) + vmcnt: A(t+1) landed; barrier.  B[s] is free.
+//       (P, T)            LDS-DMA: B pieces of tile t+2 -> B[s];  ds_read A fragments slice 1 of tile t+1 -> Z (A[s^1])
+//   interval B(t): MFMAs slice 1 = Y x V
+//       [0, RS*FM)        ds_read A fragments slice 0 of tile t+1          -> X     (from A[s^1])
+//       Q                 lgkmcnt(0) + vmcnt: B(t+1) landed; barrier.  A[s^1] is free.
+//       (Q, T)            ds_read B fragments slice 0 of tile t+1 -> U (B[s^1]);  LDS-DMA: A pieces of tile t+3 -> A[s^1]
+//   next K-step: slice-1 A set Y <-> Z swap roles (the loop is unrolled by two K-steps).
+//
+// Stream order ... B(t+1), A(t+2), B(t+2), A(t+3) ...: both waits are vmcnt(NJA + NJB) (two younger
+// half-tiles stay in flight).  Flight time: B pieces >= ~100 slots (A(t) after P -> Q of K-step t+1), A pieces
+// >= ~165 slots (B(t) after Q -> P of K-step t+2), against 66 / 127 in family "s".  LDS: the same two 64 KiB
+// stages; registers: X, Y, Z (A) + U, V (B) = 160 fragment VGPRs + 256 accumulator AGPRs.
+// Everything else (LDS image, swizzle, AGPR-resident accumulators, persistent item walk with the DMA streams
+// crossing work items, epilogues) is family "s"; the A and the B stream now have their own cursor, because
+// the A stream runs a K-step ahead of the B stream and crosses into the next work item earlier.
+#pragma once
+
+#include "hgemm_kernel_sp.hpp"
+
+// Slot-plan knobs (experiment builds: HGEMM_LIB_SUFFIX=x HGEMM_EXTRA_HIPFLAGS="-DHGEMM_SQ_SLACK=10" python build.py).
+#ifndef HGEMM_SQ_SLACK
+#define HGEMM_SQ_SLACK 6      // MFMA slots between the last leading fragment read and the sync point
+#endif
+#ifndef HGEMM_SQ_RS64
+#define HGEMM_SQ_RS64 2       // leading reads every N slots when an interval has >= 64 slots
+#endif
+#ifndef HGEMM_SQ_QORDER
+#define HGEMM_SQ_QORDER 0     // behind Q: 0 = B-fragment reads lead the A pieces, 1 = the pieces lead
+#endif
+
+namespace hgemm_mi355x {
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
+  using Base = Cfg<BM_, BN_, WM_, WN_, 16, 2>;
+  static constexpr int T   = Base::FM * Base::FN;          // MFMA slots per interval
+  static constexpr int NJA = Base::NI_A / Base::NW;        // A / B LDS-DMA pieces per wave per tile
+  static constexpr int NJB = Base::NJ - NJA;
+  static constexpr int RS  = (T >= 64) ? HGEMM_SQ_RS64 : 1; // one leading fragment read every RS slots
+  static constexpr int SLACK = (T >= 64) ? HGEMM_SQ_SLACK : 6;
+  static constexpr int P   = RS * Base::FN + SLACK;        // slot of interval A that carries sync P
+  static constexpr int Q   = RS * Base::FM + SLACK;        // slot of interval B that carries sync Q
+  // behind a sync point a DMA piece and a fragment read alternate, one item every ST slots
+  static constexpr int STA = (T - P - 1) / (NJB + Base::FM) >= 2 ? 2 : 1;
+  static constexpr int STB = (T - Q - 1) / (NJA + Base::FN) >= 2 ? 2 : 1;
+  static_assert(Base::NI % Base::NW == 0 && Base::NI_A % Base::NW == 0, "every wave owns whole A and B pieces");
+  static_assert(P + 1 + STA * (NJB + Base::FM) <= T && Q + 1 + STB * (NJA + Base::FN) <= T, "slot plan does not fit the interval");
+  static_assert(T * 4 <= 256, "accumulators live in a0..a255");
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// after sync P (interval A): item 2i = B piece i, item 2i+1 = A-fragment read i (pieces first: they need the flight time)
+// after sync Q (interval B): item 2i = B-fragment read i (needed at the top of the next interval), item 2i+1 = A piece i
+template <class CFG>
+struct SqPlan {
+  static constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T;
+  // interval A
+  static constexpr int a_piece_at(int n) {   // B piece index issued behind slot n of interval A, or -1
+    for (int i = 0; i < CFG::NJB; ++i) if (CFG::P + 1 + CFG::STA * a_item_of_piece(i) == n) return i;
+    return -1;
+  }
+  static constexpr int a_read_at(int n) {    // A-fragment (slice 1, next tile) read index behind slot n, or -1
+    for (int i = 0; i < FM; ++i) if (CFG::P + 1 + CFG::STA * a_item_of_read(i) == n) return i;
+    return -1;
+  }
+  // interleave two lists of possibly different length: alternate while both last, then the rest
+  static constexpr int a_item_of_piece(int i) { return i < FM ? 2 * i : FM + i; }
+  static constexpr int a_item_of_read(int i) { return i < CFG::NJB ? 2 * i + 1 : CFG::NJB + i; }
+  // interval B
+  static constexpr int b_item_of_read(int i) { return i < CFG::NJA ? 2 * i + HGEMM_SQ_QORDER : CFG::NJA + i; }
+  static constexpr int b_item_of_piece(int i) { return i < FN ? 2 * i + 1 - HGEMM_SQ_QORDER : FN + i; }
+  static constexpr int b_read_at(int n) {
+    for (int i = 0; i < FN; ++i) if (CFG::Q + 1 + CFG::STB * b_item_of_read(i) == n) return i;
+    return -1;
+  }
+  static constexpr int b_piece_at(int n) {
+    for (int i = 0; i < CFG::NJA; ++i) if (CFG::Q + 1 + CFG::STB * b_item_of_piece(i) == n) return i;
+    return -1;
+  }
+};
+
+// One interval.  PHASE 0 = A(t): MFMAs af x bf; leading reads -> lead (B slice 1 of tile t); behind P: B pieces
+// of tile t+2 and trailing reads -> trail (A slice 1 of tile t+1).  PHASE 1 = B(t): leading reads -> lead
+// (A slice 0 of tile t+1); behind Q: trailing reads -> trail (B slice 0 of tile t+1) and A pieces of tile t+3.
+template <class CFG, int PHASE, int NLEAD, int NTRAIL>
+__device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::FM], const f16x8 (&bf)[CFG::FN],
+                                            f16x8 (&lead)[NLEAD], const char* lead_src,
+                                            f16x8 (&trail)[NTRAIL], const char* trail_src,
+                                            __amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[CFG::NJ], int wave,
+                                            char* dma_stage, uint32_t kbyte) {
+  using PL = SqPlan<CFG>;
+  constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T, RS = CFG::RS;
+#pragma unroll
+  for (int n = 0; n < T; ++n) {
+    const int i = n / FN, j = n % FN;
+    if (n == (PHASE == 0 ? CFG::P : CFG::Q)) {
+      // every fragment read of the region about to be refilled has RETURNED (LDS returns in order, and the
+      // leading reads were the last ones issued), and my pieces of the half-tile the trailing reads are
+      // about to consume have landed; two younger half-tiles may stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<CFG::NJA + CFG::NJB>();
+      sp_sync();
+    }
+    sp_mfma(i * FN + j, bf[j], af[i]);
+    if (n % RS == 0 && n / RS < NLEAD) lead[n / RS] = *(const f16x8*)(lead_src + (n / RS) * 16 * ROW_BYTES);
+    if (PHASE == 0) {
+      const int r = PL::a_read_at(n), p = PL::a_piece_at(n);
+      if (p >= 0) sp_issue_piece<CFG>(rs, voff, dma_stage, wave, CFG::NJA + p, kbyte);
+      if (r >= 0) trail[r] = *(const f16x8*)(trail_src + r * 16 * ROW_BYTES);
+    } else {
+      const int r = PL::b_read_at(n), p = PL::b_piece_at(n);
+      if (r >= 0) trail[r] = *(const f16x8*)(trail_src + r * 16 * ROW_BYTES);
+      if (p >= 0) sp_issue_piece<CFG>(rs, voff, dma_stage, wave, p, kbyte);
+    }
+  }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+// One operand's LDS-DMA stream cursor: descriptor + per-lane offsets of the current work item's tile rows
+// and the K position inside it.  OP 0 = A (pieces 0 .. NJA-1 of voff), OP 1 = B (pieces NJA .. NJ-1).
+// Descriptors must be PROVABLY uniform (readfirstlane on the base pointer) or hipcc wraps every LDS-DMA in a
+// waterfall loop (see hgemm_kernel_sp.hpp).
+#define SQ_LOAD_ITEM(OP, ITEM)                                                                                 \
+  do {                                                                                                         \
+    /* the A stream crosses into an item first; the B stream reuses its tile coordinates (the raster map     \
+       costs several integer divisions: computed once per item, kept in SGPRs) */                            \
+    if (nxt_item != (ITEM)) {                                                                                  \
+      const TileCoord itc = map_logical(g, walk.base + walk.first + (ITEM) * walk.stride, BM, BN);             \
+      nxt_item = (ITEM);                                                                                       \
+      nxt_m0 = __builtin_amdgcn_readfirstlane(itc.m0); nxt_n0 = __builtin_amdgcn_readfirstlane(itc.n0);        \
+      nxt_kb = __builtin_amdgcn_readfirstlane(itc.k_begin * 2); nxt_nk = __builtin_amdgcn_readfirstlane(itc.nk); \
+    }                                                                                                          \
+    const uintptr_t addr = (OP) == 0 ? reinterpret_cast<uintptr_t>(g.A + (size_t)nxt_m0 * g.lda)               \
+                                     : reinterpret_cast<uintptr_t>(g.Bt + (size_t)nxt_n0 * g.ldb);             \
+    const uintptr_t uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) |     \
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);                       \
+    if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, 0xFFFFFFFFu, 0x00020000);            \
+    else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, 0xFFFFFFFFu, 0x00020000);            \
+    _Pragma("unroll") for (int j_ = ((OP) == 0 ? 0 : CFG::NJA); j_ < ((OP) == 0 ? CFG::NJA : NJ); ++j_) {      \
+      const int il_ = (OP) == 0 ? wave + j_ * CFG::NW : wave + j_ * CFG::NW - CFG::NI_A;                       \
+      const int r_ = il_ * 8 + (lane >> 3);                                                                    \
+      const int rmax_ = (OP) == 0 ? (g.M - 1 - nxt_m0) : (g.N - 1 - nxt_n0);                                   \
+      const int ld_ = (OP) == 0 ? g.lda : g.ldb;                                                               \
+      const int chunk_ = (lane & 7) ^ (((il_ & 1) << 2) | (lane >> 4));                                        \
+      voff[j_] = ((uint32_t)min(r_, rmax_) * (uint32_t)ld_ + (uint32_t)chunk_ * 8u) * 2u;                      \
+    }                                                                                                          \
+    cur[OP].kbyte = (uint32_t)nxt_kb;                                                                          \
+    cur[OP].item = (ITEM); cur[OP].kt = 0; cur[OP].nk = nxt_nk;                                                \
+  } while (0)
+
+// Move a stream one K-step on; past the last step of the last item it stays put (the branch-free DMA then
+// re-reads that valid tile into a region nobody consumes).
+#define SQ_ADVANCE(OP)                                        \
+  do {                                                        \
+    if (cur[OP].kt + 1 < cur[OP].nk) {                        \
+      ++cur[OP].kt;                                           \
+      cur[OP].kbyte += ROW_BYTES;                             \
+    } else if (cur[OP].item + 1 < walk.count) {               \
+      SQ_LOAD_ITEM(OP, cur[OP].item + 1);                     \
+    }                                                         \
+  } while (0)
+
+// One K-step on stage (step & 1).  YS = slice-1 A fragments of the current tile, ZS = where the next tile's go.
+#define SQ_K_STEP(YS, ZS)                                                                                       \
+  do {                                                                                                          \
+    char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                           \
+    char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                     \
+    sq_interval<CFG, 0, FN, FM>(fX, fU, fV, st + b_base_off + off1, ZS, nst + a_base_off + off1, rsB, voff, wave, \
+                                st, cur[1].kbyte);                                                              \
+    sq_interval<CFG, 1, FM, FN>(YS, fV, fX, nst + a_base_off + off0, fU, nst + b_base_off + off0, rsA, voff, wave, \
+                                nst, cur[0].kbyte);                                                             \
+    ++step;                                                                                                     \
+  } while (0)
+
+// EPI: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB (no single-launch split-K in this family)
+template <class CFG, int EPI>
+__global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ;
+
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / CFG::WN;
+  const int wave_n = wave % CFG::WN;
+
+  const ItemWalk walk = persistent_walk(g.items);
+  if (walk.count == 0) return;
+
+  const int l15 = lane & 15, lq = lane >> 4, sw = l15 >> 1;
+  const int off0 = l15 * ROW_BYTES + (((0 * 4 + lq) ^ sw) << 4);
+  const int off1 = l15 * ROW_BYTES + (((1 * 4 + lq) ^ sw) << 4);
+  const int a_base_off = wave_m * CFG::TM * ROW_BYTES;
+  const int b_base_off = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
+
+  sp_reserve_agprs();
+
+  // ---- the two LDS-DMA streams (A: three tiles ahead of the MFMAs, B: two) ---------------------------------
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  uint32_t voff[NJ];
+  struct Cursor { uint32_t kbyte; int item, kt, nk; } cur[2];
+  int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
+  SQ_LOAD_ITEM(0, 0);
+  SQ_LOAD_ITEM(1, 0);
+  // prologue: A(0), B(0) -> stage 0, A(1), B(1) -> stage 1
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int p = 0; p < CFG::NJA; ++p) sp_issue_piece<CFG>(rsA, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
+#pragma unroll
+    for (int p = CFG::NJA; p < NJ; ++p) sp_issue_piece<CFG>(rsB, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
+    SQ_ADVANCE(0);
+    SQ_ADVANCE(1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
+  wait_vmcnt<NJ>();                 // tile 0 landed (tile 1 may fly)
+  __builtin_amdgcn_s_barrier();
+
+  // fragment sets: X = A slice 0, Y / Z = A slice 1 (alternating), U = B slice 0, V = B slice 1
+  f16x8 fX[FM], fY[FM], fZ[FM], fU[FN], fV[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    fX[i] = *(const f16x8*)(smem + a_base_off + off0 + i * 16 * ROW_BYTES);
+    fY[i] = *(const f16x8*)(smem + a_base_off + off1 + i * 16 * ROW_BYTES);
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) fU[j] = *(const f16x8*)(smem + b_base_off + off0 + j * 16 * ROW_BYTES);
+  // the A region of stage 0 is consumed: A(2) goes there (sync = the "Q" of a virtual K-step -1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  sp_sync();
+#pragma unroll
+  for (int p = 0; p < CFG::NJA; ++p) sp_issue_piece<CFG>(rsA, voff, smem, wave, p, cur[0].kbyte);
+  SQ_ADVANCE(0);
+
+  int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
+#pragma clang loop unroll(disable)
+  for (int item = 0; item < walk.count; ++item) {
+    const TileCoord tc = map_logical(g, walk.base + walk.first + item * walk.stride, BM, BN);
+    const int nk = __builtin_amdgcn_readfirstlane(tc.nk);
+    // hot loop, two K-steps per trip: both streams stay inside this work item (the A stream issues tile t+3
+    // in K-step t and is then moved on: the trip's last move must stay inside the item, t + 5 < nk), so moving
+    // them on is a scalar add
+    int t = 0;
+#pragma clang loop unroll(disable)
+    for (; t + 5 < nk; t += 2) {
+      SQ_K_STEP(fY, fZ);
+      cur[0].kbyte += ROW_BYTES; ++cur[0].kt; cur[1].kbyte += ROW_BYTES; ++cur[1].kt;
+      SQ_K_STEP(fZ, fY);
+      cur[0].kbyte += ROW_BYTES; ++cur[0].kt; cur[1].kbyte += ROW_BYTES; ++cur[1].kt;
+    }
+    // last (up to) six K-steps: the streams may cross into the next work item
+#pragma clang loop unroll(disable)
+    for (; t + 1 < nk; t += 2) {
+      SQ_K_STEP(fY, fZ);
+      SQ_ADVANCE(0); SQ_ADVANCE(1);
+      SQ_K_STEP(fZ, fY);
+      SQ_ADVANCE(0); SQ_ADVANCE(1);
+    }
+    if (t < nk) {   // odd K-step count: one more step, then put the next tile's slice-1 fragments back into Y
+      SQ_K_STEP(fY, fZ);
+      SQ_ADVANCE(0); SQ_ADVANCE(1);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fY[i] = fZ[i];
+    }
+    // ---- epilogue of this work item (as family "s"): row by row, one fragment row live in VGPRs ----------
+    sp_mfma_drain();
+    const bool rezero = item + 1 < walk.count;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 row[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
+      if (rezero) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+      }
+      if (!HGEMM_DBG(g, 2))
+        store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wait_vmcnt<0>();  // redundant tail pieces must not outlive the workgroup's LDS allocation
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+#undef SQ_LOAD_ITEM
+#undef SQ_ADVANCE
+#undef SQ_K_STEP
+
+}  // namespace hgemm_mi355x

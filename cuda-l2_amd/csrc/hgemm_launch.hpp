@@ -1,6 +1,6 @@
 // Host-side launch thunks for the kernel instantiations listed in hgemm_configs.def.
 #pragma once
-#include "hgemm_kernel_sp.hpp"
+#include "hgemm_kernel_sq.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -59,12 +59,24 @@ void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
     HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
 }
 
+template <class CFG>
+void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
+  const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  if (epi == EPI_SLAB)   // (no single-launch split-K in this family: the host never asks for EPI_FUSED, see has_fused)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
+  else if (wide)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
+  else
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
+}
+
 struct KernelEntry {
   const char* name;
   int bm, bn, wm, wn, mi, nbuf;
   int threads, lds_bytes;
   void (*launch)(const GemmArgs&, int, hipStream_t, int, TimingSlot);
   int persistent_wgs;  // > 0: the kernel walks its work items itself, launch at most this many workgroups
+  bool has_fused;      // the family has a single-launch split-K epilogue (EPI_FUSED)
 };
 
 extern const KernelEntry g_kernel_table[];

@@ -10,9 +10,12 @@ namespace hgemm_mi355x {
   extern template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_SP(G, BM, BN, WM, WN, MI) \
   extern template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_SQ(G, BM, BN, WM, WN) \
+  extern template void launch_sq<CfgSQ<BM, BN, WM, WN>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
+#undef HGEMM_SQ
 
 // The table holds host function pointers: keep it out of the device pass.
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -23,12 +26,14 @@ thread_local LaunchTiming t_launch_timing;
   {"t" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m" HGEMM_STR(MI)  \
    "_s" HGEMM_STR(NB),                                                                         \
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
-   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0},
+   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true},
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
+#define HGEMM_SQ(G, BM, BN, WM, WN)
 const KernelEntry g_kernel_table[] = {
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
+#undef HGEMM_SQ
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
 // MI = 16 members keep their round-1 names (tuned tables refer to plans by name); MI = 32 members add "_m32"
 #define HGEMM_SP_NAME_16(BM, BN, WM, WN) "s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
@@ -36,11 +41,16 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)                                                          \
   {HGEMM_SP_NAME_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2,                                      \
    CfgSP<BM, BN, WM, WN, MI>::THREADS, CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64,                  \
-   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64))},
+   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64)), true},
+#define HGEMM_SQ(G, BM, BN, WM, WN)                                                                \
+  {"q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN), BM, BN, WM, WN, 16, 2,  \
+   CfgSQ<BM, BN, WM, WN>::THREADS, CfgSQ<BM, BN, WM, WN>::LDS_BYTES, &launch_sq<CfgSQ<BM, BN, WM, WN>>, \
+   256 * (160 * 1024 / CfgSQ<BM, BN, WM, WN>::LDS_BYTES), false},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG
 #undef HGEMM_SP
+#undef HGEMM_SQ
 const int g_num_kernels = (int)(sizeof(g_kernel_table) / sizeof(g_kernel_table[0]));
 #endif  // !__HIP_DEVICE_COMPILE__
 

@@ -1,6 +1,8 @@
 // hgemm_tune -- native (no torch) checker / autotuner / micro-benchmark for libhgemm_mi355x.so.
 //
-//   hgemm_tune check [--shapes M_N_K,...]            every geometry x split-K vs the generic kernel
+//   hgemm_tune check [--shapes M_N_K,...]            every geometry x split-K form, BIT-EXACT against an exact
+//                                                     integer reference on the reference's {0,1} inputs
+//                                                     (zero_one_correctness_check.py:65-92,263-268)
 //   hgemm_tune tune  --shapes M_N_K,... | --shape-file F  [--out F.jsonl] [--keep R] [--baselines]
 //                                                     time candidate plans, print one JSON line per shape
 //   hgemm_tune bench --shape M_N_K [--config NAME --splits S --group G] [--reps N] [--lib]
@@ -18,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -123,15 +126,19 @@ struct Plan { int cfg, splits, group_m; double model_us; };
 static bool g_plan_only = false;  // tune --plan-only
 
 // Time one callable over rotating buffer sets; returns median microseconds.
+// The callable returns the library status: a candidate that errors (bad geometry for the shape, no
+// workspace, backend failure) is reported with 1e30 us and can never win.
+constexpr double kFailedUs = 1e30;
 template <class F>
 static double time_us(F&& launch, std::vector<Buffers>& sets, int warm, int reps, hipEvent_t e0, hipEvent_t e1) {
-  for (int i = 0; i < warm; ++i) launch(sets[i % sets.size()]);
+  for (int i = 0; i < warm; ++i)
+    if (launch(sets[i % sets.size()]) != HGEMM_OK) return kFailedUs;
   HIP_OK(hipDeviceSynchronize());
   std::vector<float> t;
   for (int i = 0; i < reps; ++i) {
     Buffers& s = sets[i % sets.size()];
     HIP_OK(hipEventRecord(e0, nullptr));
-    launch(s);
+    if (launch(s) != HGEMM_OK) return kFailedUs;
     HIP_OK(hipEventRecord(e1, nullptr));
     HIP_OK(hipEventSynchronize(e1));
     float ms = 0;
@@ -143,6 +150,9 @@ static double time_us(F&& launch, std::vector<Buffers>& sets, int warm, int reps
 
 static int default_group(int cfg, const Shape& sh) { return hgemm_mi355x_default_group(cfg, sh.M, sh.N); }
 
+static std::vector<std::string> g_config_filter;  // --configs a,b,c: only these geometries are candidates
+static bool g_fused_too = false;               // --fused: also time the single-launch form of every split-K plan
+
 static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_cand) {
   std::vector<Plan> all;
   const int nc = hgemm_mi355x_num_configs();
@@ -150,6 +160,9 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
   for (int c = 0; c < nc; ++c) {
     int info[8];
     hgemm_mi355x_config_info(c, info);
+    if (!g_config_filter.empty() &&
+        std::find(g_config_filter.begin(), g_config_filter.end(), std::string(hgemm_mi355x_config_name(c))) == g_config_filter.end())
+      continue;
     if (info[0] > sh.M * 2 && info[0] > 32) continue;
     if (info[1] > sh.N * 2 && info[1] > 32) continue;
     for (int s = 1; s <= 64; s *= 2) {
@@ -157,6 +170,8 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
       const long wgs = (long)((sh.M + info[0] - 1) / info[0]) * ((sh.N + info[1] - 1) / info[1]) * s;
       if (s > 1 && wgs > 256L * 12) break;  // split-K only to fill the chip
       all.push_back({c, s, default_group(c, sh), hgemm_mi355x_model_us(c, s, sh.M, sh.N, sh.K)});
+      if (s > 1 && g_fused_too)
+        all.push_back({c, s | HGEMM_SPLITK_FUSED, default_group(c, sh), hgemm_mi355x_model_us(c, s, sh.M, sh.N, sh.K) * 1.001});
     }
   }
   std::sort(all.begin(), all.end(), [](const Plan& a, const Plan& b) { return a.model_us < b.model_us; });
@@ -170,64 +185,105 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact reference for the reference's correctness inputs (zero_one_correctness_check.py:65-73: entries are
+// 0 or 1, P(1) = 1/2, or 1/3 when max(M,N,K) > 8192).  With 0/1 operands every product and every partial
+// sum is a small integer, so C[m][n] = popcount(A_row_bits[m] & Bt_row_bits[n]) EXACTLY, whatever the
+// summation order; the expected fp16 value is that integer rounded to nearest-even -- which is what
+// (a.float() @ b.float()).half() gives (:85-90).  Outputs must match bit for bit (pass rule :263-268; the
+// reference masks |truth| > 2047 because ITS fp16-accumulate kernels round on the way -- fp32 accumulation
+// does not, so nothing is masked here).  This is a development self-check of the tool; the parity evidence
+// against the CPU oracle lives in tests/ (tests/tools/verify_plans.py, tests/test_gpu_*.py).
+struct ZeroOne {
+  std::vector<f16> a, bt;             // [M][K], [N][K]
+  std::vector<uint64_t> abits, bbits; // bit-packed rows, K/64 words (K rounded up)
+  int words;
+};
+static ZeroOne make_zero_one(const Shape& sh, uint64_t seed) {
+  ZeroOne z;
+  z.words = (sh.K + 63) / 64;
+  z.a.assign((size_t)sh.M * sh.K, (f16)0.f);
+  z.bt.assign((size_t)sh.N * sh.K, (f16)0.f);
+  z.abits.assign((size_t)sh.M * z.words, 0);
+  z.bbits.assign((size_t)sh.N * z.words, 0);
+  const bool sparse = std::max(sh.M, std::max(sh.N, sh.K)) > 8192;
+  uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  auto fill = [&](std::vector<f16>& v, std::vector<uint64_t>& bits, int rows) {
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < sh.K; ++k) {
+        const uint64_t x = next() >> 11;
+        const bool one = sparse ? (x % 3 == 0) : (x & 1);
+        if (one) { v[(size_t)r * sh.K + k] = (f16)1.f; bits[(size_t)r * z.words + k / 64] |= 1ull << (k % 64); }
+      }
+  };
+  fill(z.a, z.abits, sh.M);
+  fill(z.bt, z.bbits, sh.N);
+  return z;
+}
+
 static int cmd_check(const std::vector<Shape>& shapes) {
   int failures = 0, runs = 0;
   const int nc = hgemm_mi355x_num_configs();
   for (const Shape& sh : shapes) {
-    Buffers s;
-    alloc_set(s, sh, 1234 + sh.M + sh.N * 3 + sh.K * 7, true);
+    const ZeroOne z = make_zero_one(sh, 1234 + sh.M + sh.N * 3 + sh.K * 7);
     const size_t cn = (size_t)sh.M * sh.N;
-    f16* ref_d;
-    HIP_OK(hipMalloc(&ref_d, cn * 2));
-    int st = hgemm_mi355x_launch(-1, 1, 1, s.a, s.b, s.bt, ref_d, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
-    if (st != HGEMM_OK) { fprintf(stderr, "generic launch failed: %s\n", hgemm_mi355x_strerror(st)); return 2; }
-    HIP_OK(hipDeviceSynchronize());
-    std::vector<f16> ref(cn), got(cn);
-    HIP_OK(hipMemcpy(ref.data(), ref_d, cn * 2, hipMemcpyDeviceToHost));
-    double ref_max = 0;
-    for (size_t i = 0; i < cn; ++i) ref_max = std::max(ref_max, (double)fabsf((float)ref[i]));
-    for (int c = 0; c < nc; ++c) {
-      for (int splits : {1, 2, 3, 8}) {
-        if (splits > 1 && sh.K / 64 < splits) continue;
+    std::vector<f16> truth(cn), got(cn), b_rm((size_t)sh.K * sh.N);
+    for (int m = 0; m < sh.M; ++m)
+      for (int n = 0; n < sh.N; ++n) {
+        int acc = 0;
+        for (int w = 0; w < z.words; ++w) acc += __builtin_popcountll(z.abits[(size_t)m * z.words + w] & z.bbits[(size_t)n * z.words + w]);
+        truth[(size_t)m * sh.N + n] = (f16)(float)acc;   // int -> fp32 exact, fp32 -> fp16 round-to-nearest-even
+      }
+    for (int n = 0; n < sh.N; ++n)
+      for (int k = 0; k < sh.K; ++k) b_rm[(size_t)k * sh.N + n] = z.bt[(size_t)n * sh.K + k];
+    Buffers s;
+    HIP_OK(hipMalloc(&s.a, z.a.size() * 2));
+    HIP_OK(hipMalloc(&s.bt, z.bt.size() * 2));
+    HIP_OK(hipMalloc(&s.b, b_rm.size() * 2));
+    HIP_OK(hipMalloc(&s.c, cn * 2));
+    HIP_OK(hipMemcpy(s.a, z.a.data(), z.a.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(s.bt, z.bt.data(), z.bt.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(s.b, b_rm.data(), b_rm.size() * 2, hipMemcpyHostToDevice));
+    for (int c = HGEMM_CONFIG_RAGGED; c < nc; ++c) {
+      const char* cname = c >= 0 ? hgemm_mi355x_config_name(c) : (c == HGEMM_CONFIG_GENERIC ? "generic" : "ragged");
+      for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED}) {
+        const int sp = splits & HGEMM_SPLITK_MASK;
+        if (sp > 1 && (c < 0 || sh.K / 64 < sp)) continue;
         for (int group : {1, 4}) {
-          if (group > 1 && splits > 1) continue;
-          HIP_OK(hipMemset(s.c, 0xff, cn * 2));  // NaN pattern: unwritten outputs are caught
-          st = hgemm_mi355x_launch(c, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
-          hipError_t e = hipDeviceSynchronize();
-          ++runs;
-          if (st != HGEMM_OK || e != hipSuccess) {
-            printf("FAIL %d_%d_%d %s s=%d g=%d: status %d hip %d\n", sh.M, sh.N, sh.K, hgemm_mi355x_config_name(c), splits, group, st, (int)e);
-            ++failures;
-            if (e != hipSuccess) return 3;
-            continue;
-          }
-          HIP_OK(hipMemcpy(got.data(), s.c, cn * 2, hipMemcpyDeviceToHost));
-          double max_err = 0;
-          size_t bad = 0;
-          for (size_t i = 0; i < cn; ++i) {
-            const float g = (float)got[i], r = (float)ref[i];
-            const double err = (g == g) ? fabs((double)g - r) : 1e30;
-            // both sides accumulate in fp32 (different order) and round once to fp16
-            if (err > 2e-3 * ref_max + 1e-3) {
-              if (bad < 24 && getenv("HGEMM_CHECK_VERBOSE")) printf("   bad m=%zu n=%zu got %g ref %g\n", i / sh.N, i % sh.N, g, r);
-              ++bad;
+          if (group > 1 && sp > 1) continue;
+          if (group > 1 && c < 0) continue;
+          for (int rep = 0; rep < (sp > 1 ? 2 : 1); ++rep) {   // split-K twice: the arrival counters must come back to zero
+            HIP_OK(hipMemset(s.c, 0xff, cn * 2));  // NaN pattern: unwritten outputs are caught
+            const int st = hgemm_mi355x_launch(c, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+            hipError_t e = hipDeviceSynchronize();
+            ++runs;
+            if (st != HGEMM_OK || e != hipSuccess) {
+              printf("FAIL %d_%d_%d %s s=%d%s g=%d: status %d hip %d\n", sh.M, sh.N, sh.K, cname, sp, sp != splits ? "(fused)" : "", group, st, (int)e);
+              ++failures;
+              if (e != hipSuccess) return 3;
+              continue;
             }
-            if (err > max_err) max_err = err;
-          }
-          if (bad) {
-            printf("FAIL %d_%d_%d %s s=%d g=%d: %zu/%zu elements off, max_err %.4g (ref_max %.4g)\n", sh.M, sh.N, sh.K,
-                   hgemm_mi355x_config_name(c), splits, group, bad, cn, max_err, ref_max);
-            ++failures;
+            HIP_OK(hipMemcpy(got.data(), s.c, cn * 2, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < cn; ++i)
+              if (memcmp(&got[i], &truth[i], 2) != 0) {
+                if (bad < 8 && getenv("HGEMM_CHECK_VERBOSE")) printf("   bad m=%zu n=%zu got %g want %g\n", i / sh.N, i % sh.N, (float)got[i], (float)truth[i]);
+                ++bad;
+              }
+            if (bad) {
+              printf("FAIL %d_%d_%d %s s=%d%s g=%d: %zu/%zu elements differ from the exact result\n", sh.M, sh.N, sh.K, cname, sp,
+                     sp != splits ? "(fused)" : "", group, bad, cn);
+              ++failures;
+            }
           }
         }
       }
     }
-    HIP_OK(hipFree(ref_d));
     free_set(s);
     printf("checked %d_%d_%d\n", sh.M, sh.N, sh.K);
     fflush(stdout);
   }
-  printf("check: %d runs, %d failures\n", runs, failures);
+  printf("check: %d runs, %d failures (bit-exact against the exact integer result of 0/1 inputs)\n", runs, failures);
   return failures ? 1 : 0;
 }
 
@@ -284,10 +340,19 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       int reps = (int)std::max(3.0, std::min(30.0, 20000.0 / est_us));
       if (flops > 1.5e12) reps = 2;
       auto launch = [&](Buffers& s) {
-        hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+        return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
       };
       const double us = time_us(launch, sets, flops > 1.5e12 ? 1 : 2, reps, e0, e1);
+      if (us >= kFailedUs) {
+        fprintf(stderr, "tune: %s %s splits=%d rejected (launch status != OK)\n", key, hgemm_mi355x_config_name(p.cfg), p.splits);
+        continue;
+      }
       res.push_back({p, us});
+    }
+    if (res.empty()) {
+      fprintf(stderr, "tune: %s has no usable candidate\n", key);
+      for (auto& s : sets) free_set(s);
+      continue;
     }
     std::sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.us < b.us; });
     if (sweep_group && !res.empty()) {
@@ -298,20 +363,20 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
         Plan p = best.p;
         p.group_m = g;
         auto launch = [&](Buffers& s) {
-          hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+          return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
         };
         const double us = time_us(launch, sets, 1, flops > 1.5e12 ? 2 : std::max(3, (int)std::min(20.0, 20000.0 / best.us)), e0, e1);
-        res.push_back({p, us});
+        if (us < kFailedUs) res.push_back({p, us});
       }
       std::sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.us < b.us; });
     }
     double rb_nn = -1, rb_tn = -1, lt_nn = -1, lt_tn = -1;
     if (baselines) {
       const int reps = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
-      rb_nn = time_us([&](Buffers& s) { hgemm_rocblas_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
-      rb_tn = time_us([&](Buffers& s) { hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
-      lt_nn = time_us([&](Buffers& s) { hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
-      lt_tn = time_us([&](Buffers& s) { hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      rb_nn = time_us([&](Buffers& s) { return hgemm_rocblas_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      rb_tn = time_us([&](Buffers& s) { return hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      lt_nn = time_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+      lt_tn = time_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
     }
     double at_nn = -1, at_tn = -1;
     int at_cand_nn = 0, at_cand_tn = 0;
@@ -321,16 +386,17 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       const int reps = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
       if (hgemm_hipblaslt_autotune_find_best_nn(sh.M, sh.N, sh.K, 0) == HGEMM_OK) {
         at_cand_nn = hgemm_hipblaslt_autotune_candidates(0);
-        at_nn = time_us([&](Buffers& s) { hgemm_hipblaslt_autotune_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+        at_nn = time_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
       }
       if (hgemm_hipblaslt_autotune_find_best_tn(sh.M, sh.N, sh.K, 0) == HGEMM_OK) {
         at_cand_tn = hgemm_hipblaslt_autotune_candidates(1);
-        at_tn = time_us([&](Buffers& s) { hgemm_hipblaslt_autotune_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
+        at_tn = time_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
       }
     }
-    fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
-            sh.M, sh.N, sh.K, hgemm_mi355x_config_name(res[0].p.cfg), res[0].p.splits, res[0].p.group_m, res[0].us,
-            flops / res[0].us * 1e-6);
+    // "splits" is the value to pass to hgemm_mi355x_launch (split count | HGEMM_SPLITK_FUSED); "fused" repeats the flag
+    fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"fused\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
+            sh.M, sh.N, sh.K, hgemm_mi355x_config_name(res[0].p.cfg), res[0].p.splits, (res[0].p.splits & HGEMM_SPLITK_FUSED) ? 1 : 0,
+            res[0].p.group_m, res[0].us, flops / res[0].us * 1e-6);
     if (baselines)
       fprintf(out, ", \"rocblas_nn_us\": %.3f, \"rocblas_tn_us\": %.3f, \"hipblaslt_heur_nn_us\": %.3f, \"hipblaslt_heur_tn_us\": %.3f",
               rb_nn, rb_tn, lt_nn, lt_tn);
@@ -368,9 +434,10 @@ static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int grou
   HIP_OK(hipEventCreate(&e1));
   const int ld = g_ld_override >= 0 ? g_ld_override : sh.K;
   auto launch = [&](Buffers& s) {
-    hgemm_mi355x_launch(cfg, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, ld, ld, sh.N, nullptr);
+    return hgemm_mi355x_launch(cfg, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, ld, ld, sh.N, nullptr);
   };
   const double us = time_us(launch, sets, 3, reps, e0, e1);
+  if (us >= kFailedUs) { fprintf(stderr, "bench: launch failed\n"); return 1; }
   const double flops = 2.0 * sh.M * sh.N * (double)sh.K;
   printf("{\"mnk\": \"%d_%d_%d\", \"config\": \"%s\", \"splits\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f, \"reps\": %d}\n",
          sh.M, sh.N, sh.K, cfg >= 0 ? hgemm_mi355x_config_name(cfg) : "generic", splits, group, us, flops / us * 1e-6, reps);
@@ -397,6 +464,8 @@ int main(int argc, char** argv) {
     else if (a == "--shape-file") { auto v = read_shape_file(next()); shapes.insert(shapes.end(), v.begin(), v.end()); }
     else if (a == "--out") out_path = next();
     else if (a == "--autotune") autotune = true;
+    else if (a == "--fused") g_fused_too = true;
+    else if (a == "--configs") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) g_config_filter.push_back(t); }
     else if (a == "--plan-only") g_plan_only = true;
     else if (a == "--keep") keep = atof(next());
     else if (a == "--max-cand") max_cand = atoi(next());
@@ -422,7 +491,8 @@ int main(int argc, char** argv) {
   }
   if (mode == "check") {
     if (shapes.empty())
-      shapes = parse_shapes("64_64_64,64_4096_64,128_192_256,200_136_128,256_256_1024,320_448_512,512_1024_2048,1000_520_192");
+      shapes = parse_shapes("64_64_64,64_4096_64,128_192_256,200_136_128,256_256_1024,320_448_512,512_1024_2048,1000_520_192,"
+                            "1000_520_200,65_30_100,33_17_40,300_260_2048");
     return cmd_check(shapes);
   }
   if (mode == "tune") {

@@ -51,13 +51,15 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
 #define HGEMM_CONFIG_GENERIC (-1) /* one-output-per-thread reference kernel; reads b (row-major)        */
 #define HGEMM_CONFIG_RAGGED  (-2) /* register-staged MFMA kernel for any M,N,K / alignment; reads b_col_major */
 
-/* Split-K forms.  `splits` > 1 selects the single-launch form (fp32 partials + per-tile arrival counter, the
- * last workgroup to arrive adds the partials in split order and writes the tile -- replaces the reference's
- * atomicAdd split-K, kernels/a100_F32F16F16F32/64_256_16384.cu:149-152); OR-ing HGEMM_SPLITK_TWO_PASS into
- * `splits` selects the two-launch form (fp32 slabs [splits][M][N] + a combine kernel).  Both are
- * deterministic (fixed summation order). */
-#define HGEMM_SPLITK_TWO_PASS 0x10000
-#define HGEMM_SPLITK_MASK     0x0ffff
+/* Split-K forms.  `splits` > 1 selects the two-launch form: fp32 slabs [splits][M][N] + a combine kernel that
+ * adds them in split order.  OR-ing HGEMM_SPLITK_FUSED into `splits` selects the single-launch form instead
+ * (fp32 partials + a per-tile arrival counter; the last workgroup to arrive adds the partials in split order
+ * and writes the tile -- the deterministic counterpart of the reference's atomicAdd split-K,
+ * kernels/a100_F32F16F16F32/64_256_16384.cu:149-152).  Measured on MI355X the single-launch form only wins
+ * for the very smallest outputs (the last arriver reads the slabs alone, at 60-110 GB/s), so the tuner picks
+ * it per shape.  Both forms are deterministic (fixed summation order). */
+#define HGEMM_SPLITK_FUSED 0x10000
+#define HGEMM_SPLITK_MASK  0x0ffff
 
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)
@@ -80,7 +82,7 @@ int hgemm_mi355x_fp16(const void* a, const void* b, const void* b_col_major, voi
  *   config_id  index into the geometry table (hgemm_mi355x_config_*), HGEMM_CONFIG_GENERIC or
  *              HGEMM_CONFIG_RAGGED; a table geometry whose alignment rules the operands do not meet is
  *              served by the ragged kernel
- *   splits     split-K factor >= 1, optionally | HGEMM_SPLITK_TWO_PASS (see above); clamped to K / 64;
+ *   splits     split-K factor >= 1, optionally | HGEMM_SPLITK_FUSED (see above); clamped to K / 64;
  *              degrades to 1 when no workspace is available (lent buffer too small, out of memory)
  *   group_m    rasterisation group height in tiles (>= 1)
  * lda/ldb/ldc are row strides in elements (ldb is the row stride of b_col_major, i.e. >= K). */

@@ -99,6 +99,27 @@ def truth_numpy(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return (a.astype(np.float32) @ b.astype(np.float32)).astype(np.float16)
 
 
+def truth_prefix_k(a: np.ndarray, b: np.ndarray, ks):
+    """Truths of ALL K-prefixes of one {0,1} problem, for sweeping many (M,N,K) shapes with one pair of
+    operands: yields (K, truth_K) for K in ascending `ks`, truth_K = (a[:, :K].float() @ b[:K, :].float()).half()
+    (zero_one_correctness_check.py:85-90), and the truth of the sub-problem (M, N, K) is truth_K[:M, :N].
+    Only valid for 0/1 operands: every partial sum is an integer <= K < 2**24, exact in fp32 whatever the
+    summation order, so accumulating the K-slices incrementally is bit-identical to the one-shot product
+    (pinned in tests/test_oracle.py); total work 2*M*N*max(ks) instead of 2*M*N*sum(ks)."""
+    assert a.dtype == np.float16 and b.dtype == np.float16
+    ks = sorted(set(int(k) for k in ks))
+    assert ks and ks[-1] <= a.shape[1] == b.shape[0] and ks[-1] < 2 ** 24
+    acc = np.zeros((a.shape[0], b.shape[1]), dtype=np.float32)
+    k0 = 0
+    for k in ks:
+        if k > k0:
+            sa, sb = a[:, k0:k] , b[k0:k, :]
+            assert ((sa == 0) | (sa == 1)).all() and ((sb == 0) | (sb == 1)).all(), "truth_prefix_k is exact for {0,1} inputs only"
+            acc += sa.astype(np.float32) @ sb.astype(np.float32)
+            k0 = k
+        yield k, acc.astype(np.float16)
+
+
 def as_col_major(b: np.ndarray) -> np.ndarray:
     """[K,N] array -> array of the SAME shape whose memory is b^T (= reference as_col_major)."""
     return np.ascontiguousarray(b.T).reshape(b.shape)

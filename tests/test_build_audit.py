@@ -1,4 +1,4 @@
-"""ISA audit of the software-pipelined (SP) kernel family -- runs on CPU (hipcc cross-compiles gfx950).
+"""ISA audit of the software-pipelined kernel families ("s": hgemm_kernel_sp.hpp, "q": hgemm_kernel_sq.hpp) -- runs on CPU (hipcc cross-compiles gfx950).
 
 The SP kernels keep their 256 accumulators in explicitly named AGPRs (a[0..255], inline asm only).
 That is only sound while the compiler itself never touches AGPRs, never spills, and keeps the LDS-DMA
@@ -17,8 +17,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 def _sp_groups() -> list[int]:
-    groups = sorted({int(m.group(1)) for m in re.finditer(r"^\s*HGEMM_SP\((\d+),", (CSRC / "hgemm_configs.def").read_text(), re.M)})
-    assert groups, "no HGEMM_SP entry in hgemm_configs.def"
+    groups = sorted({int(m.group(1)) for m in re.finditer(r"^\s*HGEMM_S[PQ]\((\d+),", (CSRC / "hgemm_configs.def").read_text(), re.M)})
+    assert groups, "no HGEMM_SP / HGEMM_SQ entry in hgemm_configs.def"
     return groups
 
 
@@ -34,10 +34,10 @@ def sp_functions(tmp_path_factory):
                         "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True, timeout=900)
         text += out.read_text()
     funcs = {}
-    for m in re.finditer(r"^(_ZN12hgemm_mi355x18hgemm_tn_sp_kernel\w+):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN12hgemm_mi355x18hgemm_tn_s[pq]_kernel\w+):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
         funcs[m.group(1)] = m.group(2).splitlines()
     meta = {}
-    for m in re.finditer(r"\.amdhsa_kernel (_ZN12hgemm_mi355x18hgemm_tn_sp_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN12hgemm_mi355x18hgemm_tn_s[pq]_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
         meta[m.group(1)] = m.group(2)
     assert funcs and set(funcs) == set(meta)
     return funcs, meta

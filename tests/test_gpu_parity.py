@@ -14,6 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
+PKG_DIR = Path(__file__).resolve().parent.parent / "cuda-l2_amd"
 REL_TOL = 1e-3
 
 
@@ -52,7 +53,8 @@ def test_golden_fixtures(g, oracle, case, entry):
 @pytest.mark.parametrize("shape", [(1, 64, 64), (7, 12, 64), (64, 64, 64), (200, 136, 128), (320, 448, 512),
                                    (1000, 520, 192), (33, 17, 40), (65, 30, 100), (5, 4, 8)])
 def test_ragged_and_unaligned_shapes_match_oracle(g, oracle, shape):
-    """Edge tiles are predicated in-kernel (no harness padding); K % 64 != 0 or N % 4 != 0 take the generic kernel."""
+    """Edge tiles are predicated in-kernel (no harness padding); K % 64 != 0 or N % 4 != 0 take the
+    register-staged MFMA kernel (hgemm_kernel_rg.hpp), which pads on the way into LDS."""
     m, n, k = shape
     rng = np.random.default_rng(m * 7 + n * 3 + k)
     a, b = oracle.zero_one_inputs(m, n, k, rng)
@@ -69,10 +71,12 @@ def test_every_geometry_and_split_k_is_exact(g, oracle):
     rng = np.random.default_rng(11)
     a, b = oracle.zero_one_inputs(m, n, k, rng)
     truth = oracle.truth_numpy(a, b)
+    TWO_PASS = 0x10000   # HGEMM_SPLITK_FUSED: single-launch split-K; plain counts = slabs + combine kernel
     for cid, name in enumerate(g.config_names()):
-        for splits, group in [(1, 1), (1, 3), (2, 1), (5, 1), (16, 2)]:
-            got = g.gemm(a, b, plan=(cid, splits, group))
-            assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, splits, group)
+        for splits, group in [(1, 1), (1, 3), (2, 1), (5, 1), (16, 2), (2 | TWO_PASS, 1), (5 | TWO_PASS, 1), (16 | TWO_PASS, 2)]:
+            for _ in range(2 if splits > 1 else 1):   # twice: the per-tile arrival counters must be back at zero
+                got = g.gemm(a, b, plan=(cid, splits, group))
+                assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, splits, group)
 
 
 def test_asymmetric_identity_catches_transposes(g):
@@ -120,7 +124,7 @@ def test_guard_bars_stay_intact(g, oracle):
             assert torch.equal(fc[:bar], cc[:bar]) and torch.equal(fc[-bar:], cc[-bar:])
 
 
-def test_unaligned_pointers_fall_back_to_the_generic_kernel(g, oracle):
+def test_unaligned_pointers_take_the_register_staged_kernel(g, oracle):
     L = g.lib()
     m, n, k = 64, 64, 64
     rng = np.random.default_rng(9)
@@ -295,8 +299,213 @@ def test_hybrid_tail_schedule_is_exact_on_zero_one_inputs(g, shape):
     truth = (torch.from_numpy(a).float() @ torch.from_numpy(b).float()).half().numpy()
     assert float(np.abs(truth).max()) <= 2047
     names = g.config_names()
-    for cfg in ("s256x256_w2x2", "s128x256_w2x2"):
+    for cfg in ("s256x256_w2x2", "s128x256_w2x2", "q256x256_w2x2", "q256x128_w2x2"):
         got = g.gemm(a, b, plan=(names.index(cfg), 1, 4))
         assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), cfg
     # the library's own plan for the shape (whatever it picks) agrees as well
     assert np.array_equal(g.gemm(a, b).view(np.uint16), truth.view(np.uint16))
+
+
+@pytest.mark.parametrize("shape", [(1000, 520, 200), (65, 30, 100), (33, 17, 40), (5, 4, 8), (257, 130, 66), (129, 67, 257),
+                                   (300, 260, 2048), (2100, 2050, 328)])
+def test_ragged_kernel_and_reference_kernel_explicitly(g, oracle, shape):
+    """HGEMM_CONFIG_RAGGED (-2) and HGEMM_CONFIG_GENERIC (-1) on shapes no LDS-DMA geometry accepts: every piece
+    width of the ragged loader (K % 8 / % 4 / % 2 / odd), scalar and vector C stores, both tile sizes."""
+    m, n, k = shape
+    rng = np.random.default_rng(m + 3 * n + 5 * k)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a, b)
+    for cid in (-2, -1):
+        got = g.gemm(a, b, plan=(cid, 1, 1))
+        assert not np.isnan(got).any()
+        assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), cid
+    # a table geometry asked to run a ragged problem is served by the ragged kernel instead of failing
+    got = g.gemm(a, b, plan=(0, 1, 1))
+    assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
+
+
+def test_ragged_kernel_randn_tolerance(g, oracle):
+    m, n, k = 1000, 520, 200
+    rng = np.random.default_rng(12)
+    a = rng.standard_normal((m, k), dtype=np.float32).astype(np.float16)
+    b = rng.standard_normal((k, n), dtype=np.float32).astype(np.float16)
+    ref = a.astype(np.float32) @ b.astype(np.float32)
+    assert oracle.relative_error(g.gemm(a, b, "fp32"), ref) <= REL_TOL
+
+
+def test_split_k_on_two_streams_does_not_share_partials(g, oracle):
+    """The split-K workspace is private to the (device, stream) pair (one global workspace raced)."""
+    L = g.lib()
+    names = g.config_names()
+    cid = names.index("t64x64_w2x2_m16_s4")
+    rng = np.random.default_rng(21)
+    probs = []
+    for seed in range(2):
+        m, n, k = 192, 320, 8192
+        a_np, b_np = oracle.zero_one_inputs(m, n, k, rng)
+        probs.append((torch.from_numpy(a_np).cuda(), torch.from_numpy(b_np).cuda(), torch.from_numpy(np.ascontiguousarray(b_np.T)).cuda(),
+                      oracle.truth_numpy(a_np, b_np), (m, n, k)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for form in (16, 16 | 0x10000):
+        outs = [torch.full((p[4][0], p[4][1]), float("nan"), dtype=torch.half, device="cuda") for p in probs]
+        for rep in range(20):
+            for (a, b, bt, _, (m, n, k)), st, c in zip(probs, streams, outs):
+                assert L.hgemm_mi355x_launch(cid, form, 1, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, k, k, n,
+                                             st.cuda_stream) == 0
+        torch.cuda.synchronize()
+        for p, c in zip(probs, outs):
+            assert np.array_equal(c.cpu().numpy().view(np.uint16), p[3].view(np.uint16)), form
+
+
+def test_lent_workspace_too_small_degrades_to_no_split(g, oracle):
+    import ctypes
+
+    L = g.lib()
+    L.hgemm_mi355x_set_workspace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    m, n, k = 128, 128, 4096
+    rng = np.random.default_rng(22)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a, b)
+    cid = g.config_names().index("t64x64_w2x2_m16_s4")
+    small = torch.empty((256 << 10) + 1024, dtype=torch.uint8, device="cuda")       # counters fit, slabs do not
+    big = torch.empty(int(L.hgemm_mi355x_workspace_bytes(m, n, 8)), dtype=torch.uint8, device="cuda")
+    try:
+        assert L.hgemm_mi355x_set_workspace(small.data_ptr(), 100) == -1             # not even the counters
+        for buf in (small, big):
+            assert L.hgemm_mi355x_set_workspace(buf.data_ptr(), buf.numel()) == 0
+            for form in (8, 8 | 0x10000):
+                got = g.gemm(a, b, plan=(cid, form, 1))
+                assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
+    finally:
+        assert L.hgemm_mi355x_set_workspace(None, 0) == 0
+    assert np.array_equal(g.gemm(a, b, plan=(cid, 8, 1)).view(np.uint16), truth.view(np.uint16))
+
+
+def test_timing_hook_spans_every_kernel_of_a_two_pass_plan(g):
+    """the hook used to time the first dispatch only.  For a two-pass split-K plan (GEMM + combine) it
+    must now agree with plain event markers around the whole call (which include both kernels and add only a few
+    microseconds of queue gaps), and be clearly longer than the split GEMM kernel alone could be."""
+    L = g.lib()
+    m, n, k = 2048, 2048, 2048
+    a = torch.randn((m, k), dtype=torch.half, device="cuda")
+    b = torch.randn((k, n), dtype=torch.half, device="cuda")
+    bt = b.t().contiguous()
+    c = torch.empty((m, n), dtype=torch.half, device="cuda")
+    cid = g.config_names().index("t128x128_w2x2_m16_s3")
+    h0, h1 = L.hgemm_mi355x_event_create(), L.hgemm_mi355x_event_create()
+    call = lambda form: L.hgemm_mi355x_launch(cid, form, 4, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, k, k, n, g.stream())  # noqa: E731
+
+    def hooked(form):
+        best = 1e30
+        for _ in range(5):
+            assert L.hgemm_mi355x_time_next_launch(h0, h1) == 0
+            assert call(form) == 0
+            best = min(best, L.hgemm_mi355x_event_elapsed_us(h0, h1))
+        return best
+
+    def markers(form):
+        best = 1e30
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); assert call(form) == 0; e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3)
+        return best
+
+    for form in (1, 4, 4 | 0x10000):
+        h, mk = hooked(form), markers(form)
+        assert h > 5 and 0.6 * mk - 8 < h < 1.1 * mk + 2, (form, h, mk)
+    L.hgemm_mi355x_event_destroy(h0); L.hgemm_mi355x_event_destroy(h1)
+
+
+def test_race_screen_repeated_runs_are_bit_identical(g):
+    """SURVEY section 5 / VERDICT r1 item 10: the LDS-DMA pipelines are ordered by counted vmcnt + barriers only;
+    a mis-placed wait shows up as rare wrong tiles that come and go.  50 repeats per path on N(0,1) data, with
+    randomised raster groups, must reproduce the first result bit for bit (every path is deterministic by
+    construction, split-K included) -- and the first result is within tolerance of the fp32 reference."""
+    L = g.lib()
+    names = g.config_names()
+    rng = np.random.default_rng(31)
+    cases = [  # (config, splits, (M, N, K))
+        ("s256x256_w2x2", 1, (1024, 1536, 2048)),          # SP, persistent (24 tiles)
+        ("s256x256_w2x2_m32", 1, (1024, 1536, 2048)),      # SP, 32x32x16 MFMA
+        ("s256x256_w2x2_m32", 1, (4608, 4608, 512)),       # persistent with several items per workgroup
+        ("s256x128_w2x2", 1, (4352, 4352, 1024)),          # hybrid tail (34 x 34 tiles)
+        ("q256x256_w2x2", 1, (1024, 1536, 2048)),          # early-A split, persistent (24 tiles)
+        ("q256x256_w2x2", 1, (4608, 4608, 576)),           # ... several items per workgroup, odd K-step count (9)
+        ("q256x128_w2x2", 1, (4352, 4352, 1024)),          # ... hybrid tail
+        ("q128x256_w2x2", 3, (1024, 1024, 4096)),          # ... two-pass split-K
+        ("s256x256_w2x2", 4 | 0x10000, (1024, 1024, 4096)),# SP + single-launch split-K
+        ("s128x256_w2x2", 3, (1024, 1024, 4096)),          # SP + two-pass split-K
+        ("t64x64_w2x2_m16_s4", 16 | 0x10000, (192, 320, 8192)),  # classic 4-deep ring + single-launch split-K
+        ("t128x128_w2x2_m16_s3", 1, (2048, 2048, 1024)),   # classic 3-deep ring
+        ("t256x256_w2x4_m16_s2", 1, (2048, 2048, 1024)),   # classic 8-wave double buffer
+    ]
+    for cfg, splits, (m, n, k) in cases:
+        cid = names.index(cfg)
+        a = torch.randn((m, k), dtype=torch.half, device="cuda")
+        b = torch.randn((k, n), dtype=torch.half, device="cuda")
+        bt = b.t().contiguous()
+        c = torch.empty((m, n), dtype=torch.half, device="cuda")
+        first = None
+        for rep in range(50):
+            c.fill_(float("nan"))
+            group = int(rng.choice([1, 2, 3, 4, 8, 16]))
+            assert L.hgemm_mi355x_launch(cid, splits, group, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, k, k, n,
+                                         g.stream()) == 0
+            torch.cuda.synchronize()
+            if first is None:
+                first = c.clone()
+                ref = a.float() @ b.float()
+                rel = ((first.float() - ref).abs().max() / ref.abs().max()).item()
+                assert rel <= REL_TOL, (cfg, rel)
+            else:
+                assert torch.equal(first.view(torch.int16), c.view(torch.int16)), (cfg, splits, group, rep)
+
+
+def _plan_classes():
+    """One bucket per (kernel family, split-K form, hybrid tail) of the shipped table; >= 50 grid shapes in total,
+    every bucket represented, sizes the CPU oracle finishes in seconds."""
+    import re
+
+    rows = []
+    for ln in (PKG_DIR / "csrc" / "hgemm_tuned_table.inc").read_text().splitlines():
+        mm = re.match(r'\s*\{(\d+), (\d+), (\d+), "([^"]+)", (\d+), (\d+)\}', ln)
+        if mm:
+            rows.append((int(mm[1]), int(mm[2]), int(mm[3]), mm[4], int(mm[5]), int(mm[6])))
+    buckets = {}
+    for r in rows:
+        m, n, k, cfg, sp, _ = r
+        if 2.0 * m * n * k > 3e11:
+            continue
+        key = (cfg[0] + ("32" if cfg.endswith("m32") else ""), "1" if (sp & 0xFFFF) == 1 else ("fused" if sp & 0x10000 else "2pass"))
+        buckets.setdefault(key, []).append(r)
+    picked = []
+    per = max(4, 60 // max(1, len(buckets)))
+    for key, rs in sorted(buckets.items()):
+        rs = sorted(rs, key=lambda r: (r[0] * 7919 + r[1] * 104729 + r[2]) % 1009)   # deterministic spread
+        picked += rs[:per]
+    return picked
+
+
+def test_sample_of_grid_shapes_at_their_shipped_plans(g, oracle):
+    """>= 50 rows of the tuned table (every family x split-K form), both entry points, the reference rule:
+    0/1 inputs ({0,0,1} beyond 8192), CPU truth, mask > 2047, difference exactly 0 (zero_one_correctness_check.py:65-92,
+    263-268).  The whole grid is covered by tests/tools/verify_plans.py -> cuda-l2_amd/tuning/r02_parity_1000.jsonl."""
+    import ctypes
+
+    L = g.lib()
+    picked = _plan_classes()
+    assert len(picked) >= 50
+    rng = np.random.default_rng(41)
+    for (m, n, k, cfg, sp, gm) in picked:
+        c_, s_, g_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert L.hgemm_mi355x_plan(m, n, k, ctypes.byref(c_), ctypes.byref(s_), ctypes.byref(g_)) == 0
+        assert L.hgemm_mi355x_config_name(c_.value).decode() == cfg and (s_.value, g_.value) == (sp, gm)
+        a, b = oracle.zero_one_inputs(m, n, k, rng)
+        truth = oracle.truth_numpy(a, b)
+        for entry in ("fp32", "fp16"):
+            got = g.gemm(a, b, entry)
+            assert oracle.masked_max_diff(got, truth) == 0.0, (m, n, k, cfg, sp, gm, entry)
+            assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (m, n, k, cfg, sp, gm, entry)

@@ -115,3 +115,21 @@ def test_half_conversions_are_exact():
         want = vals.astype(np.float16).view(np.uint16)
     got = np.array([L.hgemm_oracle_float_to_half(float(v)) for v in vals], dtype=np.uint16)
     assert np.array_equal(got, want)
+
+
+def test_prefix_k_truths_are_bit_identical_to_the_one_shot_oracle():
+    """tests/tools/verify_plans.py sweeps the 1000-shape grid with one operand pair per input class and the
+    incremental K-prefix truths; for 0/1 inputs they must equal the C restatement bit for bit."""
+    rng = np.random.default_rng(3)
+    for sparse in (False, True):
+        a, b = oracle.zero_one_inputs(96, 80, 640, rng, force_sparse=sparse)
+        ks = [64, 128, 320, 640]
+        seen = []
+        for k, t in oracle.truth_prefix_k(a, b, ks):
+            seen.append(k)
+            for (m, n) in [(96, 80), (33, 17), (64, 64)]:
+                ref = oracle.truth_f32acc(np.ascontiguousarray(a[:m, :k]), np.ascontiguousarray(b[:k, :n]))
+                assert np.array_equal(t[:m, :n].view(np.uint16), ref.view(np.uint16))
+        assert seen == ks
+    with pytest.raises(AssertionError):
+        list(oracle.truth_prefix_k(np.full((4, 64), 0.5, np.float16), np.ones((64, 4), np.float16), [64]))
