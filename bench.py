@@ -1,25 +1,29 @@
 """bench.py -- headline benchmark of the MI355X HGEMM hot path (driver contract: one JSON line).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload baseline3|M_N_K,...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload M_N_K[:fp16|fp32]]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): the three single-GPU shapes BASELINE.json names, each in the accumulate
-mode it is quoted in -- 64x4096x64 fp32-acc (configs[1]), 512x4096x4096 fp32-acc (configs[3]),
-4096x4096x4096 fp16-acc (configs[2]) -- fp16 N(0,1) operands already resident in HBM.  A "step" is
-one pass over the three GEMMs through the C ABI (hgemm_mi355x_fp32 / _fp16, the entry points behind
-cuda_l2_mi355x_*).  K steps are issued back to back between barrier + device sync on both sides;
-value = total FLOPs of all ranks / max-over-ranks time, in TFLOP/s.  A single GEMM never spans
-GPUs, so N > 1 runs N independent replicas (weak scaling, no collective on the data path).
+Workload (config.workload): BASELINE.json configs[2], the 4096x4096x4096 fp16-accumulate HGEMM -- the single-GPU
+configuration whose MFMA utilisation BASELINE.json asks for (configs[1], 64x4096x64, is a 7-microsecond
+launch-bound call; it and configs[3] are reported per shape in `shapes`).  A "step" is one pass of the hot path
+over one batch of synthetic input: --batch (default 1024) independent GEMM problems of that shape, one C-ABI call
+each (hgemm_mi355x_fp16, the entry point behind cuda_l2_mi355x_fp16), fp16 N(0,1) operands already resident in
+HBM (rotating buffer sets, so successive calls do not re-hit L2 / MALL).  A step is ~0.1 s, so the default K = 20
+timed steps are a >= 2 s steady-state region behind W = 5 warm-up steps (the board's power limiter settles within
+the first milliseconds).  K steps are issued back to back between barrier + device sync on both sides;
+value = total FLOPs of all ranks / max-over-ranks time, in TFLOP/s.  A single GEMM never spans GPUs, so N > 1 runs
+N independent replicas (weak scaling, no collective on the data path).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (the 4096^3 GEMM, MFMA-bound): 2MNK / mean launch duration, measured
-                live with HIP events attached to every such dispatch of the timed region (on the
-                launch stream, hipExtLaunchKernel start/stop events), vs 2.5 PFLOP/s
-  cpu_baseline  the reference's CPU oracle expression (fp32 torch.matmul on the host, rounded to
-                fp16) timed on rank 0 at N=1 over a bounded sample of the same shapes
-  shapes        per-shape device-timed TFLOP/s of ours and of hipBLASLt (heuristic, tn and nn) and
-                rocBLAS, plus the reference-style host wall-clock (sync either side of each call)
+  roofline      the workload's kernel (MFMA-bound): 2MNK / mean launch duration, measured live with HIP events that
+                ride on the dispatch packets of a sample of the timed region's launches (every 16th; on the launch
+                stream, hipExtLaunchKernel start/stop events), vs the 2.5 PFLOP/s dense fp16 MFMA peak
+  cpu_baseline  the reference's CPU oracle expression (fp32 torch.matmul on the host, rounded to fp16) timed on
+                rank 0 at N=1 over a bounded sample of the same shape
+  shapes        BASELINE.json's three single-GPU shapes: device-timed TFLOP/s of ours, hipBLASLt heuristic AND
+                autotune (tn, nn), rocBLAS; the reference-style host wall-clock (sync either side of each call);
+                a roofline entry per shape
 """
 from __future__ import annotations
 
@@ -41,8 +45,10 @@ for p in (str(REPO), str(PKG)):
         sys.path.insert(0, p)
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_TBPS = 8.0            # HBM3E spec, MI355X_MICROARCH.md
 BASELINE3 = [("64_4096_64", "fp32"), ("512_4096_4096", "fp32"), ("4096_4096_4096", "fp16")]
-DOMINANT = "4096_4096_4096"
+WORKLOAD = ("4096_4096_4096", "fp16")
+EVENT_STRIDE = 16              # every 16th launch of the timed region carries dispatch-attached timing events
 
 
 def load_library():
@@ -54,7 +60,8 @@ def load_library():
     vp, ci = ctypes.c_void_p, ctypes.c_int
     for name in ("hgemm_mi355x_fp32", "hgemm_mi355x_fp16"):
         getattr(lib, name).argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
-    for name in ("hgemm_rocblas_nn", "hgemm_rocblas_tn", "hgemm_hipblaslt_heuristic_nn", "hgemm_hipblaslt_heuristic_tn"):
+    for name in ("hgemm_rocblas_nn", "hgemm_rocblas_tn", "hgemm_hipblaslt_heuristic_nn", "hgemm_hipblaslt_heuristic_tn",
+                 "hgemm_hipblaslt_autotune_nn", "hgemm_hipblaslt_autotune_tn"):
         getattr(lib, name).argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     lib.hgemm_mi355x_config_name.restype = ctypes.c_char_p
     lib.hgemm_mi355x_event_create.restype = vp
@@ -116,6 +123,15 @@ def launch_ours(lib, prob: Problem, stream: int):
     return c
 
 
+def settle(fn, seconds: float) -> None:
+    """Run fn back to back for `seconds` (clock / power state and caches in steady state before a measurement)."""
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+
+
 def device_time_us(fn, reps: int) -> float:
     """Median device time of fn() with HIP events on the current stream."""
     evs = []
@@ -142,13 +158,28 @@ def wall_time_us(fn, reps: int) -> float:
     return tot / reps * 1e6
 
 
+def roofline_entry(p, us: float, traffic=None) -> dict:
+    """Which roof bounds the shape (arithmetic intensity vs the ridge 2.5 PF / 8 TB/s = 312 flop/B) and how close
+    the measured launch is.  Algorithmic work: 2MNK flop; 2(MK + KN + MN) bytes (A, B read once, C written once)."""
+    ai = p.flops / p.bytes
+    if ai >= MFMA_F16_PEAK_TFLOPS / HBM_PEAK_TBPS:
+        ach = p.flops / us * 1e-6
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "arithmetic_intensity": round(ai, 1)}
+    ach = p.bytes / us * 1e-6  # TB/s
+    return {"bound": "hbm", "achieved": round(ach * 1e3, 2), "peak": HBM_PEAK_TBPS * 1e3, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_TBPS, 4), "traffic": traffic, "arithmetic_intensity": round(ai, 1)}
+
+
 def per_shape_report(lib, probs, stream) -> dict:
     acc_id = {"fp32": 0, "fp16": 1}
     out = {}
     lib.hgemm_rocblas_init()
     lib.hgemm_hipblaslt_heuristic_init()
+    lib.hgemm_hipblaslt_autotune_init()
+    os.environ.setdefault("HGEMM_AUTOTUNE_MAX_SECONDS", "1.0")
     for p in probs:
-        reps = 20 if p.flops < 1e11 else 10
+        reps = 40 if p.flops < 1e11 else 20
 
         def base(fname, use_bt):
             def run():
@@ -158,23 +189,47 @@ def per_shape_report(lib, probs, stream) -> dict:
             return run
 
         ours = lambda: launch_ours(lib, p, stream)  # noqa: E731
-        for f in (ours, base("hgemm_hipblaslt_heuristic_tn", True), base("hgemm_hipblaslt_heuristic_nn", False)):
-            f()  # warm (algo selection, workspace)
-        torch.cuda.synchronize()
-        row = {"acc": p.acc, "ours_us": device_time_us(ours, reps), "ours_wall_us": wall_time_us(ours, reps),
-               "hipblaslt_heur_tn_us": device_time_us(base("hgemm_hipblaslt_heuristic_tn", True), reps),
-               "hipblaslt_heur_nn_us": device_time_us(base("hgemm_hipblaslt_heuristic_nn", False), reps),
-               "rocblas_tn_us": device_time_us(base("hgemm_rocblas_tn", True), reps),
-               "hipblaslt_heur_tn_wall_us": wall_time_us(base("hgemm_hipblaslt_heuristic_tn", True), reps)}
+        auto_ok = (lib.hgemm_hipblaslt_autotune_find_best_tn(p.m, p.n, p.k, acc_id[p.acc]) == 0 and
+                   lib.hgemm_hipblaslt_autotune_find_best_nn(p.m, p.n, p.k, acc_id[p.acc]) == 0)
+        fns = {"ours": ours, "hipblaslt_heur_tn": base("hgemm_hipblaslt_heuristic_tn", True),
+               "hipblaslt_heur_nn": base("hgemm_hipblaslt_heuristic_nn", False), "rocblas_tn": base("hgemm_rocblas_tn", True)}
+        if auto_ok:
+            fns["hipblaslt_auto_tn"] = base("hgemm_hipblaslt_autotune_tn", True)
+            fns["hipblaslt_auto_nn"] = base("hgemm_hipblaslt_autotune_nn", False)
+        row = {"acc": p.acc}
+        # interleaved rounds (all functions share the clock / thermal history), median of the per-round medians
+        for f in fns.values():
+            settle(f, 0.15)
+        rounds = {k: [] for k in fns}
+        for _ in range(3):
+            for k, f in fns.items():
+                settle(f, 0.05)
+                rounds[k].append(device_time_us(f, reps))
+        for k, v in rounds.items():
+            row[k + "_us"] = sorted(v)[1]
+        row["ours_wall_us"] = wall_time_us(ours, reps)
+        lt = {k: row[k + "_us"] for k in fns if k.startswith("hipblaslt")}
+        best_lt = min(lt, key=lt.get)
+        row["hipblaslt_best"] = best_lt
+        row["hipblaslt_best_wall_us"] = wall_time_us(fns[best_lt], reps)
         row["ours_tflops"] = p.flops / row["ours_us"] * 1e-6
-        row["hipblaslt_heur_max_tflops"] = p.flops / min(row["hipblaslt_heur_tn_us"], row["hipblaslt_heur_nn_us"]) * 1e-6
-        row["speedup_vs_hipblaslt_heur_max"] = min(row["hipblaslt_heur_tn_us"], row["hipblaslt_heur_nn_us"]) / row["ours_us"]
-        row["speedup_wall_vs_hipblaslt_heur_tn"] = row["hipblaslt_heur_tn_wall_us"] / row["ours_wall_us"]
+        heur = min(row["hipblaslt_heur_tn_us"], row["hipblaslt_heur_nn_us"])
+        row["hipblaslt_heur_max_tflops"] = p.flops / heur * 1e-6
+        row["speedup_vs_hipblaslt_heur_max"] = heur / row["ours_us"]
+        if auto_ok:
+            auto = min(row["hipblaslt_auto_tn_us"], row["hipblaslt_auto_nn_us"])
+            row["hipblaslt_auto_max_tflops"] = p.flops / auto * 1e-6
+            row["speedup_vs_hipblaslt_auto_max"] = min(auto, heur) / row["ours_us"]   # strongest hipBLASLt variant
+        row["speedup_wall_vs_hipblaslt_best"] = row["hipblaslt_best_wall_us"] / row["ours_wall_us"]
+        row["hipblaslt_compute16_fallback"] = bool(lib.hgemm_hipblaslt_compute16_fallback(0, 1) == 1)
         cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.hgemm_mi355x_plan(p.m, p.n, p.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
         name = lib.hgemm_mi355x_config_name(cfg.value)
-        row["plan"] = {"config": name.decode() if name else "generic", "splits": sp.value, "group_m": gm.value}
+        row["plan"] = {"config": name.decode() if name else "ragged", "splits": sp.value & 0xFFFF, "fused_split_k": bool(sp.value & 0x10000),
+                       "group_m": gm.value}
+        row["roofline"] = roofline_entry(p, row["ours_us"], measured_traffic_bytes(p.mnk))
         out[p.mnk] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in row.items()}
+    lib.hgemm_hipblaslt_autotune_destroy()
     lib.hgemm_hipblaslt_heuristic_destroy()
     lib.hgemm_rocblas_destroy()
     return out
@@ -204,24 +259,29 @@ def cpu_baseline(workload, seconds: float = 12.0) -> dict:
             "sample": f"{passes} passes of the workload's shapes as (a.float() @ b.float()).half() on the host in {dt:.1f} s"}
 
 
-def measured_traffic_bytes() -> float | None:
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, if any."""
-    f = REPO / "profiles" / "pmc_summary.json"
-    if f.exists():
-        try:
-            return float(json.loads(f.read_text())["dominant_kernel"]["hbm_bytes_per_launch"])
-        except Exception:
-            return None
+def measured_traffic_bytes(mnk: str) -> float | None:
+    """HBM bytes per launch of the shape's kernel from the committed rocprofv3 PMC summaries (profiles/), if any."""
+    for name in ("pmc_summary.json", f"r02_pmc_{mnk}.json", f"r01_pmc_{mnk}.json"):
+        f = REPO / "profiles" / name
+        if f.exists():
+            try:
+                d = json.loads(f.read_text())["dominant_kernel"]
+                if d.get("mnk") == mnk:
+                    return float(d["hbm_bytes_per_launch"])
+            except Exception:
+                continue
     return None
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__)
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", type=str, default="baseline3", help="baseline3 or comma separated M_N_K[:fp16|fp32]")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="GEMM problems per step (one C-ABI call each)")
+    ap.add_argument("--workload", type=str, default=":".join(WORKLOAD), help="M_N_K[:fp16|fp32] (default: BASELINE.json configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the per-shape report (ours / hipBLASLt / rocBLAS on BASELINE's shapes)")
     args = ap.parse_args(argv)
 
     if not torch.cuda.is_available():
@@ -241,32 +301,27 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    if args.workload == "baseline3":
-        workload = BASELINE3
-    else:
-        workload = [(w.split(":")[0], (w.split(":") + ["fp32"])[1]) for w in args.workload.split(",") if w]
+    mnk, acc = (args.workload.split(":") + ["fp32"])[:2]
     lib = load_library()
     torch.manual_seed(1234 + rank)
-    probs = [Problem(mnk, acc, device) for mnk, acc in workload]
-    dominant = max(probs, key=lambda p: p.flops)
+    prob = Problem(mnk, acc, device)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # HIP events for every dominant-kernel launch of the timed region.  They ride on the kernel's own
-    # dispatch packet (hgemm_mi355x_time_next_launch -> hipExtLaunchKernel on the launch stream), so
-    # they measure the kernel exactly as rocprofv3 does and put no marker packets between launches.
-    pool = [(lib.hgemm_mi355x_event_create(), lib.hgemm_mi355x_event_create()) for _ in range(args.steps)]
+    # HIP events for a sample of the timed region's launches.  They ride on the kernel's own dispatch packet
+    # (hgemm_mi355x_time_next_launch -> hipExtLaunchKernel on the launch stream), so they measure the kernel
+    # exactly as rocprofv3 does and put no marker packets between launches.
+    n_ev = max(1, (args.steps * args.batch + EVENT_STRIDE - 1) // EVENT_STRIDE)
+    pool = [(lib.hgemm_mi355x_event_create(), lib.hgemm_mi355x_event_create()) for _ in range(n_ev)]
     if any(e0 is None or e1 is None for e0, e1 in pool):
         raise RuntimeError("hipEventCreate failed")
 
-    def step(events=None):
-        for p in probs:
-            if events is not None and p is dominant:
+    def step(events=None, first_launch=0):
+        for i in range(args.batch):
+            if events is not None and (first_launch + i) % EVENT_STRIDE == 0:
                 e0, e1 = pool[len(events)]
                 check(lib, lib.hgemm_mi355x_time_next_launch(e0, e1), "time_next_launch")
-                launch_ours(lib, p, stream)
                 events.append((e0, e1))
-            else:
-                launch_ours(lib, p, stream)
+            launch_ours(lib, prob, stream)
 
     for _ in range(args.warmup):
         step()
@@ -276,40 +331,49 @@ def main(argv=None):
     torch.cuda.synchronize()
     events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
+    for s_i in range(args.steps):
+        step(events, s_i * args.batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    step_flops = sum(p.flops for p in probs)
-    elapsed, total_flops = reduce_over_ranks(elapsed, step_flops * args.steps, device)
+    elapsed, total_flops = reduce_over_ranks(elapsed, prob.flops * args.batch * args.steps, device)
 
-    dom_us = sum(lib.hgemm_mi355x_event_elapsed_us(e0, e1) for e0, e1 in events) / len(events)
+    durs = sorted(lib.hgemm_mi355x_event_elapsed_us(e0, e1) for e0, e1 in events)
+    dom_us = sum(durs) / len(durs)
     for e0, e1 in pool:
         lib.hgemm_mi355x_event_destroy(e0)
         lib.hgemm_mi355x_event_destroy(e1)
-    achieved = dominant.flops / dom_us * 1e-6
+    roof = roofline_entry(prob, dom_us, measured_traffic_bytes(prob.mnk))
+    roof.update({"kernel": prob.mnk, "avg_launch_us": round(dom_us, 2), "median_launch_us": round(durs[len(durs) // 2], 2),
+                 "launches_timed": len(durs), "algorithmic_flops_per_launch": prob.flops, "algorithmic_bytes_per_launch": prob.bytes})
+    cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.hgemm_mi355x_plan(prob.m, prob.n, prob.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
+    cname = lib.hgemm_mi355x_config_name(cfg.value)
     result = {
         "metric": "HGEMM TFLOP/s", "value": round(total_flops / elapsed * 1e-12, 3), "unit": "TFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "+".join(f"{m}:{a}-acc" for m, a in workload) + " fp16 N(0,1) operands resident in HBM, "
-                   "one C-ABI GEMM call per shape per step, replicas per GPU",
-                   "accumulate": "fp32 MFMA (both modes; CDNA4 has no fp16-accumulate MFMA)"},
-        "roofline": {"bound": "mfma", "kernel": dominant.mnk, "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": measured_traffic_bytes(),
-                     "avg_launch_us": round(dom_us, 2), "algorithmic_flops_per_launch": dominant.flops,
-                     "algorithmic_bytes_per_launch": dominant.bytes},
+        "config": {"workload": f"{mnk} {acc}-acc HGEMM (BASELINE.json configs[2]); step = {args.batch} independent GEMM problems, one C-ABI "
+                               "call each, fp16 N(0,1) operands resident in HBM; replicas per GPU",
+                   "batch": args.batch, "timed_region_s": round(elapsed, 3),
+                   "accumulate": "fp32 MFMA (both modes; CDNA4 has no fp16-accumulate MFMA)",
+                   "plan": {"config": cname.decode() if cname else "ragged", "splits": sp.value & 0xFFFF, "group_m": gm.value}},
+        "roofline": roof,
     }
     if rank == 0:
-        result["shapes"] = per_shape_report(lib, probs, stream)
-        sp = [v["speedup_vs_hipblaslt_heur_max"] for v in result["shapes"].values()]
-        result["geomean_speedup_vs_hipblaslt_heuristic_max"] = round(math.exp(sum(map(math.log, sp)) / len(sp)), 4)
+        if not args.no_shapes:
+            others = [Problem(m_, a_, device) for m_, a_ in BASELINE3 if (m_, a_) != (mnk, acc)]
+            result["shapes"] = per_shape_report(lib, others + [prob], stream)
+            sp_h = [v["speedup_vs_hipblaslt_heur_max"] for v in result["shapes"].values()]
+            result["geomean_speedup_vs_hipblaslt_heuristic_max"] = round(math.exp(sum(map(math.log, sp_h)) / len(sp_h)), 4)
+            sp_a = [v["speedup_vs_hipblaslt_auto_max"] for v in result["shapes"].values() if "speedup_vs_hipblaslt_auto_max" in v]
+            if sp_a:
+                result["geomean_speedup_vs_hipblaslt_autotune_max"] = round(math.exp(sum(map(math.log, sp_a)) / len(sp_a)), 4)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(workload)
+            result["cpu_baseline"] = cpu_baseline([(mnk, acc)])
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -172,6 +172,7 @@ void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     // Do not pick tiles that mostly compute padding.
     if (e.bm > M * 2 && e.bm > 32) continue;
     if (e.bn > N * 2 && e.bn > 32) continue;
+    if (K % e.kgran != 0) continue;
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && ksteps / s < 4) break;
       const double t = model_us(e, M, N, K, s);
@@ -217,6 +218,10 @@ int hgemm_mi355x_config_info(int id, int out[8]) {
   out[0] = e.bm; out[1] = e.bn; out[2] = e.wm; out[3] = e.wn;
   out[4] = e.mi; out[5] = e.nbuf; out[6] = e.threads; out[7] = e.lds_bytes;
   return HGEMM_OK;
+}
+
+int hgemm_mi355x_config_k_granularity(int id) {
+  return (id >= 0 && id < g_num_kernels) ? g_kernel_table[id].kgran : 1;
 }
 
 int hgemm_mi355x_config_by_name(const char* name) {
@@ -328,7 +333,10 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     g.tiles_m = (M + e.bm - 1) / e.bm;
     g.tiles_n = (N + e.bn - 1) / e.bn;
     const long tiles = (long)g.tiles_m * g.tiles_n;
-    const int ksteps = K / BK;
+    // pipeline stages of this geometry along K (BK = 64, or 128 for the "_k128" members)
+    if (K % e.kgran != 0) return HGEMM_ERR_BAD_ARG;
+    const int kgran = e.kgran;
+    const int ksteps = K / kgran;
     splits = std::max(1, std::min(splits, ksteps));
     const int steps_per_split = (ksteps + splits - 1) / splits;
     splits = (ksteps + steps_per_split - 1) / steps_per_split;  // no empty split
@@ -339,7 +347,8 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     // no split-K: the plan degrades to splits = 1 instead of failing.
     int epi = EPI_C16;
     if (splits > 1) {
-      const bool fused = want_fused && tiles <= (long)kMaxFusedTiles && e.has_fused;
+      const bool fused = want_fused && tiles <= (long)kMaxFusedTiles && e.has_fused &&
+                         (double)tiles * splits * e.bm * e.bn * sizeof(float) < 2147483648.0;   // 32-bit slab offsets
       const size_t slab_bytes = fused ? (size_t)tiles * splits * e.bm * e.bn * sizeof(float)
                                       : (size_t)splits * M * N * sizeof(float);
       unsigned* counters = nullptr;
@@ -354,7 +363,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
       }
     }
     const int per = (ksteps + splits - 1) / splits;
-    g.k_chunk = per * BK;
+    g.k_chunk = per * kgran;
     g.splits = splits;
     const long grid = tiles * splits;
     g.items = (int)grid;
@@ -382,7 +391,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
         const double tile_us = model_us(e, e.bm, e.bn, K, 1) - kLaunchUs;
         if (0.6 * tile_us - tile_us / S > 25.0) {
           GemmArgs t = g;
-          t.tail_first = (int)full; t.tail_tiles = (int)tail; t.splits = S; t.k_chunk = per_t * BK;
+          t.tail_first = (int)full; t.tail_tiles = (int)tail; t.splits = S; t.k_chunk = per_t * kgran;
           t.items = (int)tail * S;
           unsigned* unused = nullptr;
           // (no workspace just means: no hybrid schedule)

@@ -291,36 +291,51 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const TileCoord& t
 // 64_256_16384.cu:149-152, and its per-call memset + convert kernels) ---------------------------------------
 // Every (split, tile) work item writes its fp32 partial to its own compact slab in the kernel's LANE ORDER
 // (quad x of thread tid at slab[(x * THREADS + tid) * 4]: every store instruction is one contiguous 1 KiB
-// per wave), publishes it with one agent-scope release, and draws a ticket from the tile's arrival counter.
-// The workgroup that draws the last ticket acquires once, adds the `splits` slabs IN SPLIT ORDER (so the
-// result does not depend on arrival order: deterministic, unlike atomics) and writes the fp16 tile.  Nobody
-// waits for anybody, so the scheme needs no co-residency and cannot deadlock; placement only affects speed.
-// The last arriver resets the counter, so the counters are zero between launches (the host zeroes them once
-// at allocation).  Protocol = cdna_hip_programming.md section 6, guideline 16 (fence first, ticket second).
+// per wave) and draws a ticket from the tile's arrival counter.  The workgroup that draws the last ticket
+// adds the `splits` slabs IN SPLIT ORDER (so the result does not depend on arrival order: deterministic,
+// unlike atomics) and writes the fp16 tile.  Nobody waits for anybody, so the scheme needs no co-residency
+// and cannot deadlock; placement only affects speed.  The last arriver resets the counter, so the counters
+// are zero between launches (the host zeroes them once at allocation).
+// Visibility (cdna_hip_programming.md section 6, guideline 16, write-through form): the slabs are written
+// with sc1 (write-through) stores and read with sc1 loads, so they bypass the non-coherent per-XCD L2s; each
+// wave drains its stores (vmcnt(0)), a workgroup barrier collects the waves, then ONE relaxed agent-scope
+// fetch_add publishes the arrival.  No release / acquire fences: an agent-scope release is a whole-L2
+// write-back (buffer_wbl2) per workgroup -- measured +7..12 us per GEMM with the fence form.
+#if defined(__HIP_DEVICE_COMPILE__)
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int kAuxSc1 = 16;   // buffer aux operand: bit 4 = sc1 (system-coherent / write-through)
+
+// slab byte offset of quad x of thread tid in work item `item` (32-bit: the host only takes the fused form
+// when all slabs together stay below 2 GiB)
 template <int THREADS>
-__device__ __forceinline__ float* fused_slot(float* slab, int x, int tid) {
-  return slab + ((size_t)x * THREADS + tid) * 4;
+__device__ __forceinline__ uint32_t fused_off(int item, int slab_elems, int x, int tid) {
+  return ((uint32_t)item * (uint32_t)slab_elems + ((uint32_t)x * THREADS + tid) * 4u) * 4u;
+}
+__device__ __forceinline__ void fused_store(__amdgpu_buffer_rsrc_t rs, uint32_t off, const f32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, kAuxSc1);
+}
+__device__ __forceinline__ f32x4 fused_load(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAuxSc1));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fused_rsrc(const GemmArgs& g) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)g.partial, 0, 0xFFFFFFFFu, 0x00020000);
 }
 
 // Called by every thread of the workgroup after its slab stores were issued.  `lds_flag` is a word of the
 // kernel's (single) LDS array that no in-flight LDS-DMA targets.  True in every thread of the last arriver.
 __device__ __forceinline__ bool fused_publish_and_vote(const GemmArgs& g, int tile, volatile unsigned* lds_flag, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my slab stores have left the wave
-  __syncthreads();                                    // ... and so have every other wave's
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my write-through slab stores are acknowledged
+  __syncthreads();                                    // ... and so are every other wave's
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restates the post-write-back wait where hipcc may drop it
     const unsigned old = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = (old + 1u == (unsigned)g.splits);
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (last) __hip_atomic_store(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *lds_flag = last ? 1u : 0u;
   }
   __syncthreads();
   return *lds_flag != 0u;
 }
+#endif  // __HIP_DEVICE_COMPILE__
 
 // The buffer-resource builtins only exist in the device pass; the host pass just needs the
 // kernel stubs, so device bodies are compiled under __HIP_DEVICE_COMPILE__ only.
@@ -465,8 +480,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
   (void)split;
   if constexpr (EPI == EPI_FUSED) {
     constexpr int NQ = (MI == 16) ? 1 : 4;   // f32x4 quads per accumulator tile
-    const size_t slab_elems = (size_t)BM * BN;
-    float* mine = g.partial + (size_t)tc.item * slab_elems;
+    constexpr int SLAB = BM * BN;
+    const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -474,21 +489,19 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-          *(f32x4*)fused_slot<CFG::THREADS>(mine, (i * FN + j) * NQ + q, tid) = v;
+          fused_store(rsP, fused_off<CFG::THREADS>(tc.item, SLAB, (i * FN + j) * NQ + q, tid), v);
         }
     if (!fused_publish_and_vote(g, tc.tile, (volatile unsigned*)smem, tid)) return;
     // last arriver: slabs of this tile are item = s * tiles + tile, s = 0 .. splits-1, added in that order
-    const size_t stride = (size_t)g.tiles_m * g.tiles_n * slab_elems;
-    const float* base = g.partial + (size_t)tc.tile * slab_elems;
+    const int tiles = g.tiles_m * g.tiles_n;
     for (int sidx = 0; sidx < g.splits; ++sidx) {
-      float* sl = const_cast<float*>(base) + (size_t)sidx * stride;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
-            const f32x4 v = *(const f32x4*)fused_slot<CFG::THREADS>(sl, (i * FN + j) * NQ + q, tid);
+            const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, SLAB, (i * FN + j) * NQ + q, tid));
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = (sidx == 0) ? v[e] : acc[i][j][q * 4 + e] + v[e];
           }

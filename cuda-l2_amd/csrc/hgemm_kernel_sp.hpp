@@ -401,8 +401,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
     sp_mfma_drain();
     const bool rezero = item + 1 < walk.count;   // (the last tile's accumulators are not needed again)
     const int m_wave = tc.m0 + wave_m * CFG::TM, n_wave = tc.n0 + wave_n * CFG::TN;
-    float* const my_slab = (EPI == SP_EPI_FUSED) ? g.partial + (size_t)tc.item * ((size_t)BM * BN) : nullptr;
-    (void)m_wave; (void)n_wave; (void)my_slab;
+    const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
+    (void)m_wave; (void)n_wave; (void)rsP;
     if constexpr (MI == 16) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
         }
         if constexpr (EPI == SP_EPI_FUSED) {
 #pragma unroll
-          for (int j = 0; j < FN; ++j) *(f32x4*)fused_slot<CFG::THREADS>(my_slab, i * FN + j, tid) = row[j];
+          for (int j = 0; j < FN; ++j) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, BM * BN, i * FN + j, tid), row[j]);
         } else {
           if (!HGEMM_DBG(g, 2))
             store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
         }
         if constexpr (EPI == SP_EPI_FUSED) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) *(f32x4*)fused_slot<CFG::THREADS>(my_slab, x * 4 + q, tid) = qd[q];
+          for (int q = 0; q < 4; ++q) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, BM * BN, x * 4 + q, tid), qd[q]);
         } else if constexpr (EPI == SP_EPI_SLAB) {
           const int m = m_wave + i * 32 + (lane & 31);
 #pragma unroll
@@ -454,9 +454,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
       // single-launch split-K: publish my slab, draw a ticket; the last arriver of this tile adds the slabs
       // in split order and writes the fp16 tile (accumulators are not involved: they belong to the next item)
       if (fused_publish_and_vote(g, tc.tile, (volatile unsigned*)(smem + CFG::FLAG_OFF), tid)) {
-        const size_t slab_elems = (size_t)BM * BN;
-        const size_t stride = (size_t)g.tiles_m * g.tiles_n * slab_elems;
-        float* base = g.partial + (size_t)tc.tile * slab_elems;
+        const int tiles = g.tiles_m * g.tiles_n;
         if constexpr (MI == 16) {
 #pragma unroll 1
           for (int i = 0; i < FM; ++i) {
@@ -464,7 +462,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
             for (int sidx = 0; sidx < g.splits; ++sidx) {
 #pragma unroll
               for (int j = 0; j < FN; ++j) {
-                const f32x4 v = *(const f32x4*)fused_slot<CFG::THREADS>(base + (size_t)sidx * stride, i * FN + j, tid);
+                const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
                 row[j] = (sidx == 0) ? v : row[j] + v;
               }
             }
@@ -478,7 +476,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
             for (int sidx = 0; sidx < g.splits; ++sidx) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)fused_slot<CFG::THREADS>(base + (size_t)sidx * stride, x * 4 + q, tid);
+                const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, x * 4 + q, tid));
                 qd[q] = (sidx == 0) ? v : qd[q] + v;
               }
             }

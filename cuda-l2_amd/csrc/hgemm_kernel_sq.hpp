@@ -46,22 +46,35 @@
 
 namespace hgemm_mi355x {
 
-template <int BM_, int BN_, int WM_, int WN_>
+// KT = BK=64 sub-tiles per pipeline stage.  KT = 1: a stage holds K = 64, an interval is one K=32 MFMA slice.
+// KT = 2: a stage holds K = 128 as two complete BK=64 images ([A rows][B rows] each, same swizzle), an interval
+// is one sub-tile (two K=32 slices): twice the MFMA slots between sync points, which is what lets a 128x128
+// tile (16 MFMA tiles per wave) amortise its two barriers per stage.
+template <int BM_, int BN_, int WM_, int WN_, int KT_ = 1>
 struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
   using Base = Cfg<BM_, BN_, WM_, WN_, 16, 2>;
-  static constexpr int T   = Base::FM * Base::FN;          // MFMA slots per interval
-  static constexpr int NJA = Base::NI_A / Base::NW;        // A / B LDS-DMA pieces per wave per tile
-  static constexpr int NJB = Base::NJ - NJA;
+  static constexpr int KT  = KT_;
+  static constexpr int SL  = KT;                           // K=32 MFMA slices per interval
+  static constexpr int SUB_BYTES   = Base::STAGE_BYTES;    // one BK=64 image: (BM + BN) rows x 128 B
+  static constexpr int STAGE_BYTES = KT * SUB_BYTES;
+  static constexpr int LDS_BYTES   = 2 * STAGE_BYTES;
+  static constexpr int NFA = Base::FM * SL, NFB = Base::FN * SL;   // fragment reads per operand per interval
+  static constexpr int T   = Base::FM * Base::FN * SL;     // MFMA slots per interval
+  static constexpr int PA  = Base::NI_A / Base::NW;        // LDS-DMA pieces per wave per operand per sub-tile
+  static constexpr int PB  = Base::NJ - PA;
+  static constexpr int NJA = KT * PA, NJB = KT * PB;       // ... per stage
   static constexpr int RS  = (T >= 64) ? HGEMM_SQ_RS64 : 1; // one leading fragment read every RS slots
-  static constexpr int SLACK = (T >= 64) ? HGEMM_SQ_SLACK : 6;
-  static constexpr int P   = RS * Base::FN + SLACK;        // slot of interval A that carries sync P
-  static constexpr int Q   = RS * Base::FM + SLACK;        // slot of interval B that carries sync Q
+  static constexpr int SLACK = (T >= 64) ? HGEMM_SQ_SLACK : (T >= 32 ? 6 : 2);
+  static constexpr int P   = RS * NFB + SLACK;             // slot of interval A that carries sync P
+  static constexpr int Q   = RS * NFA + SLACK;             // slot of interval B that carries sync Q
   // behind a sync point a DMA piece and a fragment read alternate, one item every ST slots
-  static constexpr int STA = (T - P - 1) / (NJB + Base::FM) >= 2 ? 2 : 1;
-  static constexpr int STB = (T - Q - 1) / (NJA + Base::FN) >= 2 ? 2 : 1;
+  static constexpr int STA = (T - P - 1) / (NJB + NFA) >= 2 ? 2 : 1;
+  static constexpr int STB = (T - Q - 1) / (NJA + NFB) >= 2 ? 2 : 1;
+  static_assert(KT == 1 || KT == 2, "one or two BK=64 sub-tiles per stage");
   static_assert(Base::NI % Base::NW == 0 && Base::NI_A % Base::NW == 0, "every wave owns whole A and B pieces");
-  static_assert(P + 1 + STA * (NJB + Base::FM) <= T && Q + 1 + STB * (NJA + Base::FN) <= T, "slot plan does not fit the interval");
-  static_assert(T * 4 <= 256, "accumulators live in a0..a255");
+  static_assert(P + 1 + STA * (NJB + NFA) <= T && Q + 1 + STB * (NJA + NFB) <= T, "slot plan does not fit the interval");
+  static_assert(Base::FM * Base::FN * 4 <= 256, "accumulators live in a0..a255");
+  static_assert(LDS_BYTES + 64 <= 160 * 1024, "LDS budget");
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -69,7 +82,7 @@ struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
 // after sync Q (interval B): item 2i = B-fragment read i (needed at the top of the next interval), item 2i+1 = A piece i
 template <class CFG>
 struct SqPlan {
-  static constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T;
+  static constexpr int FM = CFG::NFA, FN = CFG::NFB, T = CFG::T;   // fragment reads per operand, MFMA slots
   // interval A
   static constexpr int a_piece_at(int n) {   // B piece index issued behind slot n of interval A, or -1
     for (int i = 0; i < CFG::NJB; ++i) if (CFG::P + 1 + CFG::STA * a_item_of_piece(i) == n) return i;
@@ -95,20 +108,36 @@ struct SqPlan {
   }
 };
 
-// One interval.  PHASE 0 = A(t): MFMAs af x bf; leading reads -> lead (B slice 1 of tile t); behind P: B pieces
-// of tile t+2 and trailing reads -> trail (A slice 1 of tile t+1).  PHASE 1 = B(t): leading reads -> lead
-// (A slice 0 of tile t+1); behind Q: trailing reads -> trail (B slice 0 of tile t+1) and A pieces of tile t+3.
-template <class CFG, int PHASE, int NLEAD, int NTRAIL>
-__device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::FM], const f16x8 (&bf)[CFG::FN],
-                                            f16x8 (&lead)[NLEAD], const char* lead_src,
-                                            f16x8 (&trail)[NTRAIL], const char* trail_src,
+// LDS-DMA piece `idx` (0 .. KT*P_op - 1) of operand OP for the stage at `stage`: sub-tile idx / P_op, 8-row
+// block idx % P_op of this wave; the source advances 128 B per sub-tile.
+template <class CFG, int OP>
+__device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[CFG::NJ], char* stage,
+                                               int wave, int idx, uint32_t kbyte) {
+  constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
+  const int sub = idx / POP, p = (OP == 0 ? 0 : CFG::PA) + idx % POP;
+  lds_void_t* dst = (lds_void_t*)(stage + sub * CFG::SUB_BYTES + (wave + p * CFG::NW) * 1024);
+  // (the sub-tile's 128 B go into the scalar offset: the instruction's immediate offset would also be added to
+  // the LDS address of an LDS-DMA)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff[p], kbyte + sub * ROW_BYTES, 0, HGEMM_DMA_AUX);
+}
+
+// One interval.  PHASE 0 = A(t): MFMAs af x bf; leading reads -> lead (B fragments of the second half of tile t);
+// behind P: B pieces of tile t+2 and trailing reads -> trail (A fragments of the second half of tile t+1).
+// PHASE 1 = B(t): leading reads -> lead (A fragments of the first half of tile t+1); behind Q: trailing reads ->
+// trail (B fragments of the first half of tile t+1) and A pieces of tile t+3.
+// Fragment read r of a set: slice r / F reads from src0 / src1, row block r % F.
+template <class CFG, int PHASE>
+__device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f16x8 (&bf)[CFG::NFB],
+                                            f16x8 (&lead)[PHASE == 0 ? CFG::NFB : CFG::NFA], const char* lead0, const char* lead1,
+                                            f16x8 (&trail)[PHASE == 0 ? CFG::NFA : CFG::NFB], const char* trail0, const char* trail1,
                                             __amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[CFG::NJ], int wave,
                                             char* dma_stage, uint32_t kbyte) {
   using PL = SqPlan<CFG>;
   constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T, RS = CFG::RS;
+  constexpr int NLEAD = PHASE == 0 ? CFG::NFB : CFG::NFA, FLEAD = PHASE == 0 ? FN : FM, FTRAIL = PHASE == 0 ? FM : FN;
 #pragma unroll
   for (int n = 0; n < T; ++n) {
-    const int i = n / FN, j = n % FN;
+    const int u = n / (FM * FN), i = (n / FN) % FM, j = n % FN;   // K=32 slice, accumulator tile (i, j)
     if (n == (PHASE == 0 ? CFG::P : CFG::Q)) {
       // every fragment read of the region about to be refilled has RETURNED (LDS returns in order, and the
       // leading reads were the last ones issued), and my pieces of the half-tile the trailing reads are
@@ -117,16 +146,19 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::FM], const f1
       wait_vmcnt<CFG::NJA + CFG::NJB>();
       sp_sync();
     }
-    sp_mfma(i * FN + j, bf[j], af[i]);
-    if (n % RS == 0 && n / RS < NLEAD) lead[n / RS] = *(const f16x8*)(lead_src + (n / RS) * 16 * ROW_BYTES);
+    sp_mfma(i * FN + j, bf[u * FN + j], af[u * FM + i]);
+    if (n % RS == 0 && n / RS < NLEAD) {
+      const int r = n / RS;
+      lead[r] = *(const f16x8*)((r / FLEAD ? lead1 : lead0) + (r % FLEAD) * 16 * ROW_BYTES);
+    }
     if (PHASE == 0) {
       const int r = PL::a_read_at(n), p = PL::a_piece_at(n);
-      if (p >= 0) sp_issue_piece<CFG>(rs, voff, dma_stage, wave, CFG::NJA + p, kbyte);
-      if (r >= 0) trail[r] = *(const f16x8*)(trail_src + r * 16 * ROW_BYTES);
+      if (p >= 0) sq_issue_piece<CFG, 1>(rs, voff, dma_stage, wave, p, kbyte);
+      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * 16 * ROW_BYTES);
     } else {
       const int r = PL::b_read_at(n), p = PL::b_piece_at(n);
-      if (r >= 0) trail[r] = *(const f16x8*)(trail_src + r * 16 * ROW_BYTES);
-      if (p >= 0) sp_issue_piece<CFG>(rs, voff, dma_stage, wave, p, kbyte);
+      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * 16 * ROW_BYTES);
+      if (p >= 0) sq_issue_piece<CFG, 0>(rs, voff, dma_stage, wave, p, kbyte);
     }
   }
 }
@@ -144,7 +176,8 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::FM], const f1
       const TileCoord itc = map_logical(g, walk.base + walk.first + (ITEM) * walk.stride, BM, BN);             \
       nxt_item = (ITEM);                                                                                       \
       nxt_m0 = __builtin_amdgcn_readfirstlane(itc.m0); nxt_n0 = __builtin_amdgcn_readfirstlane(itc.n0);        \
-      nxt_kb = __builtin_amdgcn_readfirstlane(itc.k_begin * 2); nxt_nk = __builtin_amdgcn_readfirstlane(itc.nk); \
+      nxt_kb = __builtin_amdgcn_readfirstlane(itc.k_begin * 2);                                                \
+      nxt_nk = __builtin_amdgcn_readfirstlane(itc.nk / CFG::KT);   /* stages of K = 64 * KT (host: K chunk % (64 KT) == 0) */ \
     }                                                                                                          \
     const uintptr_t addr = (OP) == 0 ? reinterpret_cast<uintptr_t>(g.A + (size_t)nxt_m0 * g.lda)               \
                                      : reinterpret_cast<uintptr_t>(g.Bt + (size_t)nxt_n0 * g.ldb);             \
@@ -152,7 +185,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::FM], const f1
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);                       \
     if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, 0xFFFFFFFFu, 0x00020000);            \
     else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, 0xFFFFFFFFu, 0x00020000);            \
-    _Pragma("unroll") for (int j_ = ((OP) == 0 ? 0 : CFG::NJA); j_ < ((OP) == 0 ? CFG::NJA : NJ); ++j_) {      \
+    _Pragma("unroll") for (int j_ = ((OP) == 0 ? 0 : CFG::PA); j_ < ((OP) == 0 ? CFG::PA : NJ); ++j_) {        \
       const int il_ = (OP) == 0 ? wave + j_ * CFG::NW : wave + j_ * CFG::NW - CFG::NI_A;                       \
       const int r_ = il_ * 8 + (lane >> 3);                                                                    \
       const int rmax_ = (OP) == 0 ? (g.M - 1 - nxt_m0) : (g.N - 1 - nxt_n0);                                   \
@@ -170,31 +203,36 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::FM], const f1
   do {                                                        \
     if (cur[OP].kt + 1 < cur[OP].nk) {                        \
       ++cur[OP].kt;                                           \
-      cur[OP].kbyte += ROW_BYTES;                             \
+      cur[OP].kbyte += CFG::KT * ROW_BYTES;                   \
     } else if (cur[OP].item + 1 < walk.count) {               \
       SQ_LOAD_ITEM(OP, cur[OP].item + 1);                     \
     }                                                         \
   } while (0)
 
-// One K-step on stage (step & 1).  YS = slice-1 A fragments of the current tile, ZS = where the next tile's go.
+// One pipeline step (K = 64 * KT) on stage (step & 1).  YS = second-half A fragments of the current tile,
+// ZS = where the next tile's go.  Fragment source of interval h, slice u: KT = 1: the stage image, chunk group h;
+// KT = 2: sub-tile image h, chunk group u.
+#define SQ_FRAG(STAGE, OPOFF, H, U) ((STAGE) + (CFG::KT == 2 ? (H) * CFG::SUB_BYTES : 0) + (OPOFF) + ((CFG::KT == 2 ? (U) : (H)) ? off1 : off0))
 #define SQ_K_STEP(YS, ZS)                                                                                       \
   do {                                                                                                          \
     char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                           \
     char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                     \
-    sq_interval<CFG, 0, FN, FM>(fX, fU, fV, st + b_base_off + off1, ZS, nst + a_base_off + off1, rsB, voff, wave, \
-                                st, cur[1].kbyte);                                                              \
-    sq_interval<CFG, 1, FM, FN>(YS, fV, fX, nst + a_base_off + off0, fU, nst + b_base_off + off0, rsA, voff, wave, \
-                                nst, cur[0].kbyte);                                                             \
+    sq_interval<CFG, 0>(fX, fU, fV, SQ_FRAG(st, b_base_off, 1, 0), SQ_FRAG(st, b_base_off, 1, 1),               \
+                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), rsB, voff, wave, st, cur[1].kbyte); \
+    sq_interval<CFG, 1>(YS, fV, fX, SQ_FRAG(nst, a_base_off, 0, 0), SQ_FRAG(nst, a_base_off, 0, 1),             \
+                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), rsA, voff, wave, nst, cur[0].kbyte); \
     ++step;                                                                                                     \
   } while (0)
 
-// EPI: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB (no single-launch split-K in this family)
+// EPI: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB / SP_EPI_FUSED (as family "s")
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ;
+  constexpr int NFA = CFG::NFA, NFB = CFG::NFB;
 
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
+  // the two stages + one word for the single-launch split-K vote (ONE LDS object, see hgemm_kernel_sp.hpp)
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -224,39 +262,39 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int p = 0; p < CFG::NJA; ++p) sp_issue_piece<CFG>(rsA, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
+    for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
 #pragma unroll
-    for (int p = CFG::NJA; p < NJ; ++p) sp_issue_piece<CFG>(rsB, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
+    for (int p = 0; p < CFG::NJB; ++p) sq_issue_piece<CFG, 1>(rsB, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
     SQ_ADVANCE(0);
     SQ_ADVANCE(1);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
-  wait_vmcnt<NJ>();                 // tile 0 landed (tile 1 may fly)
+  wait_vmcnt<CFG::NJA + CFG::NJB>();   // tile 0 landed (tile 1 may fly)
   __builtin_amdgcn_s_barrier();
 
-  // fragment sets: X = A slice 0, Y / Z = A slice 1 (alternating), U = B slice 0, V = B slice 1
-  f16x8 fX[FM], fY[FM], fZ[FM], fU[FN], fV[FN];
+  // fragment sets: X = A first half, Y / Z = A second half (alternating), U = B first half, V = B second half
+  f16x8 fX[NFA], fY[NFA], fZ[NFA], fU[NFB], fV[NFB];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    fX[i] = *(const f16x8*)(smem + a_base_off + off0 + i * 16 * ROW_BYTES);
-    fY[i] = *(const f16x8*)(smem + a_base_off + off1 + i * 16 * ROW_BYTES);
+  for (int r = 0; r < NFA; ++r) {
+    fX[r] = *(const f16x8*)(SQ_FRAG(smem, a_base_off, 0, r / FM) + (r % FM) * 16 * ROW_BYTES);
+    fY[r] = *(const f16x8*)(SQ_FRAG(smem, a_base_off, 1, r / FM) + (r % FM) * 16 * ROW_BYTES);
   }
 #pragma unroll
-  for (int j = 0; j < FN; ++j) fU[j] = *(const f16x8*)(smem + b_base_off + off0 + j * 16 * ROW_BYTES);
+  for (int r = 0; r < NFB; ++r) fU[r] = *(const f16x8*)(SQ_FRAG(smem, b_base_off, 0, r / FN) + (r % FN) * 16 * ROW_BYTES);
   // the A region of stage 0 is consumed: A(2) goes there (sync = the "Q" of a virtual K-step -1)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   sp_sync();
 #pragma unroll
-  for (int p = 0; p < CFG::NJA; ++p) sp_issue_piece<CFG>(rsA, voff, smem, wave, p, cur[0].kbyte);
+  for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voff, smem, wave, p, cur[0].kbyte);
   SQ_ADVANCE(0);
 
   int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
 #pragma clang loop unroll(disable)
   for (int item = 0; item < walk.count; ++item) {
     const TileCoord tc = map_logical(g, walk.base + walk.first + item * walk.stride, BM, BN);
-    const int nk = __builtin_amdgcn_readfirstlane(tc.nk);
+    const int nk = __builtin_amdgcn_readfirstlane(tc.nk / CFG::KT);
     // hot loop, two K-steps per trip: both streams stay inside this work item (the A stream issues tile t+3
     // in K-step t and is then moved on: the trip's last move must stay inside the item, t + 5 < nk), so moving
     // them on is a scalar add
@@ -264,9 +302,9 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma clang loop unroll(disable)
     for (; t + 5 < nk; t += 2) {
       SQ_K_STEP(fY, fZ);
-      cur[0].kbyte += ROW_BYTES; ++cur[0].kt; cur[1].kbyte += ROW_BYTES; ++cur[1].kt;
+      cur[0].kbyte += CFG::KT * ROW_BYTES; ++cur[0].kt; cur[1].kbyte += CFG::KT * ROW_BYTES; ++cur[1].kt;
       SQ_K_STEP(fZ, fY);
-      cur[0].kbyte += ROW_BYTES; ++cur[0].kt; cur[1].kbyte += ROW_BYTES; ++cur[1].kt;
+      cur[0].kbyte += CFG::KT * ROW_BYTES; ++cur[0].kt; cur[1].kbyte += CFG::KT * ROW_BYTES; ++cur[1].kt;
     }
     // last (up to) six K-steps: the streams may cross into the next work item
 #pragma clang loop unroll(disable)
@@ -280,11 +318,13 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       SQ_K_STEP(fY, fZ);
       SQ_ADVANCE(0); SQ_ADVANCE(1);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) fY[i] = fZ[i];
+      for (int r = 0; r < NFA; ++r) fY[r] = fZ[r];
     }
     // ---- epilogue of this work item (as family "s"): row by row, one fragment row live in VGPRs ----------
     sp_mfma_drain();
     const bool rezero = item + 1 < walk.count;
+    const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
+    (void)rsP;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       __builtin_amdgcn_sched_barrier(0);
@@ -295,10 +335,33 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma unroll
         for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
       }
-      if (!HGEMM_DBG(g, 2))
-        store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+      if constexpr (EPI == SP_EPI_FUSED) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, BM * BN, i * FN + j, tid), row[j]);
+      } else {
+        if (!HGEMM_DBG(g, 2))
+          store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (EPI == SP_EPI_FUSED) {
+      if (fused_publish_and_vote(g, tc.tile, (volatile unsigned*)(smem + CFG::LDS_BYTES), tid)) {
+        const int tiles = g.tiles_m * g.tiles_n;
+#pragma unroll 1
+        for (int i = 0; i < FM; ++i) {
+          f32x4 row[FN];
+          for (int sidx = 0; sidx < g.splits; ++sidx) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
+              row[j] = (sidx == 0) ? v : row[j] + v;
+            }
+          }
+          store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   wait_vmcnt<0>();  // redundant tail pieces must not outlive the workgroup's LDS allocation
 #endif  // __HIP_DEVICE_COMPILE__
@@ -307,5 +370,6 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #undef SQ_LOAD_ITEM
 #undef SQ_ADVANCE
 #undef SQ_K_STEP
+#undef SQ_FRAG
 
 }  // namespace hgemm_mi355x

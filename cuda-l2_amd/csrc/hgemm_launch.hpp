@@ -62,7 +62,9 @@ void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
 template <class CFG>
 void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
   const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-  if (epi == EPI_SLAB)   // (no single-launch split-K in this family: the host never asks for EPI_FUSED, see has_fused)
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
     HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
   else if (wide)
     HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
@@ -77,6 +79,8 @@ struct KernelEntry {
   void (*launch)(const GemmArgs&, int, hipStream_t, int, TimingSlot);
   int persistent_wgs;  // > 0: the kernel walks its work items itself, launch at most this many workgroups
   bool has_fused;      // the family has a single-launch split-K epilogue (EPI_FUSED)
+  int kgran;           // K granularity of one pipeline stage (64, or 128 for the BK=128 members): K and every
+                       // split-K chunk must be a multiple
 };
 
 extern const KernelEntry g_kernel_table[];

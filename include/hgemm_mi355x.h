@@ -106,6 +106,10 @@ const char* hgemm_mi355x_config_name(int config_id);
 /* out[0..7] = BM, BN, WM, WN, MI, NBUF, threads, lds_bytes */
 int hgemm_mi355x_config_info(int config_id, int out[8]);
 int hgemm_mi355x_config_by_name(const char* name);
+/* K granularity of a geometry's pipeline stage (64, or 128 for the "_k128" members): hgemm_mi355x_launch
+ * returns HGEMM_ERR_BAD_ARG for a table geometry when K is not a multiple (the planner never picks one);
+ * 1 for the special ids. */
+int hgemm_mi355x_config_k_granularity(int config_id);
 
 /* Split-K workspace.  Default: the library keeps one private device buffer per (device, stream) pair that
  * issued a split-K plan and grows it on first use of a bigger plan only (never in steady state; growing

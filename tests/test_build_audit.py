@@ -69,7 +69,7 @@ def test_sp_kernels_do_not_spill_and_leave_room_for_the_agprs(sp_functions):
         accum = re.search(r"\.amdhsa_accum_offset (\d+)", meta[name])
         assert m and accum
         assert int(m.group(1)) - int(accum.group(1)) == 256, f"{name}: expected 256 AGPRs"
-        assert int(accum.group(1)) <= 240, f"{name}: {accum.group(1)} VGPRs leaves no headroom below 256"
+        assert int(accum.group(1)) <= 256, f"{name}: {accum.group(1)} VGPRs: the allocator would have to spill into the reserved AGPRs"
         assert int(m.group(1)) <= 512
 
 
