@@ -15,6 +15,7 @@
 #include <rocblas/rocblas.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -241,7 +242,19 @@ int autotune_find(bool tn, int M, int N, int K, int acc) {
   std::vector<hipblasLtMatmulHeuristicResult_t> cands;
   int st = lt_prepare(g_auto, p, tn, M, N, K, acc, 100, cands);
   if (st != HGEMM_OK) return st;
-  const int n_algo = (int)cands.size();
+  int n_algo = (int)cands.size();
+  {
+    // Time box, part 1 (before anything is allocated): when one round over all candidates would already take more
+    // than a fifth of HGEMM_AUTOTUNE_MAX_SECONDS (estimated at 400 TFLOP/s), only the heuristic's top candidates
+    // compete (never fewer than 4).  With the default box of 30 s this does not trigger below ~1e13 flop.
+    const char* env = getenv("HGEMM_AUTOTUNE_MAX_SECONDS");
+    const double box = env ? atof(env) : 30.0;
+    const double est_s = 2.0 * M * N * (double)K / 4.0e14;
+    if (box > 0 && est_s * n_algo > box / 5.0) {
+      n_algo = std::max(4, std::min(n_algo, (int)(box / 5.0 / est_s)));
+      cands.resize(n_algo);
+    }
+  }
 
   f16 *a = nullptr, *b = nullptr, *c = nullptr;
   if (hipMalloc(&a, (size_t)M * K * 2) != hipSuccess || hipMalloc(&b, (size_t)K * N * 2) != hipSuccess ||
@@ -256,20 +269,14 @@ int autotune_find(bool tn, int M, int N, int K, int acc) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
 
+  // The reference runs 50 warm-up + 100 timed rounds over every candidate (hgemm_cublaslt_auto_tuning.cu:108-306).
+  // HGEMM_AUTOTUNE_MAX_SECONDS (default 30) is a REAL time box: the first round is timed on the host clock
+  // (it includes the operand refill, the per-call event sync and hipBLASLt's own host path, which dominate for
+  // small problems) and the round counts shrink to fit, never below 2 + 3.
   int warm = 50, timed = 100;
-  {
-    // Time-box: estimate one GEMM at ~400 TFLOP/s and shrink the round counts if the
-    // reference's 150 rounds x n_algo would exceed the budget.
-    const char* env = getenv("HGEMM_AUTOTUNE_MAX_SECONDS");
-    const double budget = env ? atof(env) : 30.0;
-    const double est_ms = std::max(0.01, 2.0 * M * N * (double)K / 4.0e11);
-    const double full = (warm + timed) * (n_algo + 1) * est_ms * 1e-3;
-    if (budget > 0 && full > budget) {
-      const double f = budget / full;
-      warm = std::max(3, (int)(warm * f));
-      timed = std::max(5, (int)(timed * f));
-    }
-  }
+  const char* box_env = getenv("HGEMM_AUTOTUNE_MAX_SECONDS");
+  const double budget = box_env ? atof(box_env) : 30.0;
+  const auto t_begin = std::chrono::steady_clock::now();
   std::vector<std::vector<float>> times(n_algo);
   std::vector<bool> failed(n_algo, false);
   std::mt19937 rng(std::random_device{}());
@@ -296,6 +303,15 @@ int autotune_find(bool tn, int M, int N, int K, int acc) {
       float ms = 0.f;
       hipEventElapsedTime(&ms, e0, e1);
       if (round >= warm) times[idx].push_back(ms);
+    }
+    if (round == 0 && budget > 0) {
+      const double t_round = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+      const double full = t_round * (warm + timed);
+      if (full > budget) {
+        const double f = budget / full;
+        warm = std::max(2, (int)(warm * f));
+        timed = std::max(3, (int)(timed * f));
+      }
     }
   }
   int best = -1;

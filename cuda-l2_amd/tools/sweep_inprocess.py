@@ -142,17 +142,20 @@ def eval_shape(hgemm, mnk: str, args, rng: np.random.Generator) -> dict:
 
 
 def cpu_matmul_tflops(mnk: str, seconds: float) -> dict:
-    """torch.matmul(a_half, b_half) on the host cores (the reference's perf_func 'matmul' on --device cpu)."""
+    """The reference's CPU expression (a.cpu().float() @ b.cpu().float()).half() (zero_one_correctness_check.py:85-90)
+    on the host cores.  (torch.matmul on fp16 CPU tensors, what `--device cpu --perf_func matmul` times, runs an
+    unvectorised path on this host: ~0.001 TFLOP/s; the fp32 expression is the meaningful CPU baseline.)"""
     m, n, k = parse_mnk(mnk)
     a = torch.randn((m, k)).half()
     b = torch.randn((k, n)).half()
     t0 = time.time()
     it = 0
     while it < 1 or time.time() - t0 < seconds:
-        torch.matmul(a, b)
+        torch.matmul(a.float(), b.float()).half()
         it += 1
     dt = (time.time() - t0) / it
-    return {"cpu_matmul_tflops": 2.0 * m * n * k / dt * 1e-12, "cpu_iterations": it, **cpu_cores()}
+    return {"cpu_matmul_tflops": 2.0 * m * n * k / dt * 1e-12, "cpu_iterations": it, "cpu_expression": "(a.float() @ b.float()).half()",
+            **cpu_cores()}
 
 
 def run(args, shapes: list[str], rank: int, gpu: int) -> dict:

@@ -184,124 +184,6 @@ def tile_of(bid: int, tiles_m: int, tiles_n: int, group_m: int):
     return split, first_m + tin % gm, tin // gm
 
 
-# ---- ping-pong family (hgemm_kernel_pp.hpp): K=32 half-tiles, 64-B LDS rows ------------------------
-class GeometryPP:
-    def __init__(self, bm, bn, wm, wn):
-        self.BM, self.BN, self.WM, self.WN, self.MI = bm, bn, wm, wn, 16
-        self.NW = wm * wn
-        self.TM, self.TN = bm // wm, bn // wn
-        self.FM, self.FN = self.TM // 16, self.TN // 16
-        self.NIH_A = bm // 16
-        self.NIH = (bm + bn) // 16
-        self.P = self.NIH // self.NW
-        self.HALF_BYTES = (bm + bn) * 64
-
-
-def stage_half(geo: GeometryPP, a_tile, bt_tile, k0, m_valid, n_valid):
-    lds = np.full(geo.HALF_BYTES // 2, np.nan, dtype=np.float32)
-    for wave in range(geo.NW):
-        for p in range(geo.P):
-            piece = wave + p * geo.NW
-            is_a = piece < geo.NIH_A
-            il = piece if is_a else piece - geo.NIH_A
-            for lane in range(64):
-                r = il * 16 + (lane >> 2)
-                rc = min(r, (m_valid - 1) if is_a else (n_valid - 1))
-                chunk = (lane & 3) ^ ((lane >> 5) << 1)
-                src = a_tile if is_a else bt_tile
-                vals = src[rc, k0 + chunk * 8: k0 + chunk * 8 + 8]
-                dst = (piece * 1024 + lane * 16) // 2
-                lds[dst:dst + 8] = vals
-    return lds
-
-
-def run_tile_pp(geo: GeometryPP, A, Bt, m0, n0):
-    M, K = A.shape
-    N = Bt.shape[0]
-    assert K % BK == 0
-    a_tile, bt_tile = A[m0:], Bt[n0:]
-    acc = np.zeros((geo.NW, geo.FM, geo.FN, 64, 4))
-    conflicts = 0
-    for k0 in range(0, K, 32):
-        lds = stage_half(geo, a_tile, bt_tile, k0, M - m0, N - n0)
-        for wave in range(geo.NW):
-            wave_m, wave_n = wave // geo.WN, wave % geo.WN
-            frag = [(lane & 15) * 64 + ((((lane >> 4) ^ (((lane & 15) >> 3) << 1))) << 4) for lane in range(64)]
-            a_off = wave_m * geo.TM * 64
-            b_off = geo.BM * 64 + wave_n * geo.TN * 64
-            af, bf = [], []
-            for i in range(geo.FM):
-                addrs = [a_off + i * 16 * 64 + frag[lane] for lane in range(64)]
-                conflicts += bank_conflict_extra_cycles(addrs)
-                af.append(np.stack([lds[x // 2:x // 2 + 8] for x in addrs]))
-            for j in range(geo.FN):
-                addrs = [b_off + j * 16 * 64 + frag[lane] for lane in range(64)]
-                conflicts += bank_conflict_extra_cycles(addrs)
-                bf.append(np.stack([lds[x // 2:x // 2 + 8] for x in addrs]))
-            for i in range(geo.FM):
-                for j in range(geo.FN):
-                    acc[wave, i, j] += mfma(16, bf[j], af[i])
-    out = {}
-    for wave in range(geo.NW):
-        wave_m, wave_n = wave // geo.WN, wave % geo.WN
-        for lane in range(64):
-            lm, ln = lane & 15, (lane >> 4) * 4
-            for i in range(geo.FM):
-                m = m0 + wave_m * geo.TM + i * 16 + lm
-                for j in range(geo.FN):
-                    n = n0 + wave_n * geo.TN + j * 16 + ln
-                    if m < M and n < N:
-                        for e in range(4):
-                            assert (m, n + e) not in out
-                            out[(m, n + e)] = acc[wave, i, j, lane, e]
-    return out, conflicts
-
-
-def pp_schedule_hazards(NU: int, P: int = 4):
-    """Replay the two-group schedule of hgemm_tn_pp_kernel as barrier-interval events and check
-    (a) a ring slot is refilled only after both groups retired their reads of its old content,
-    (b) a half-tile is read only after both groups waited for their pieces of it before a barrier.
-    Returns the list of violations (empty = schedule is hazard-free by construction)."""
-    bad = []
-    # interval in which group g runs R(u) / M(u); a phase's events happen inside that interval
-    R = lambda g, u: 2 * u + g
-    Mi = lambda g, u: 2 * u + 1 + g
-    issue_iv = {}   # (g, v) -> interval the group's pieces of half-tile v are issued in
-    landed_iv = {}  # (g, v) -> interval at whose END the group is known to have waited for v
-    for g in (0, 1):
-        for v in range(min(3, NU)):
-            issue_iv[(g, v)] = -1          # prologue
-        for u in range(NU):
-            if u + 3 < NU:
-                issue_iv[(g, u + 3)] = Mi(g, u)
-        landed_iv[(g, 0)] = -1             # prologue wait + barrier
-        for u in range(NU):
-            if u + 1 < NU:
-                # G0 waits after M(u), G1 after R(u): both are interval 2u+1
-                landed_iv[(g, u + 1)] = Mi(0, u) if g == 0 else R(1, u)
-                # counted wait correctness: younger half-tiles issued so far by this group
-                issued_upto = min(u + 3, NU - 1) if g == 0 else min(u + 2, NU - 1)
-                younger = issued_upto - (u + 1)
-                allowed = min(NU - 2 - u, 2) if g == 0 else min(NU - 2 - u, 1)
-                if allowed > younger:
-                    bad.append(("wait too weak", g, u, allowed, younger))
-    for v in range(NU):
-        for g in (0, 1):
-            # (b) read after landing: R(v) by either group must come after both groups' waits + barrier
-            for g2 in (0, 1):
-                if not landed_iv[(g2, v)] < R(g, v):
-                    bad.append(("read before landed", g, v, g2))
-            # (a) refill of slot v%4 (half-tile v) after reads of half-tile v-4 were retired:
-            # reads issued in R(g2, v-4) are retired before that group's M(v-4) MFMAs, i.e. they are
-            # complete once the group has passed the barrier ending interval Mi(g2, v-4) - 1... be
-            # conservative: require the refill interval to be > Mi(g2, v-4) - 1 + 0, i.e. >= Mi(g2, v-4)+1
-            if v >= 4:
-                for g2 in (0, 1):
-                    if not issue_iv[(g, v)] >= Mi(g2, v - 4) + 1:
-                        bad.append(("refill too early", g, v, g2, issue_iv[(g, v)], Mi(g2, v - 4)))
-    return bad
-
-
 def wide_epilogue_columns(fn: int):
     """Replay of store_tile's wide path: for each fragment pair (j, j+1) and lane, the 8 consecutive
     N offsets (inside the wave tile) the lane stores after v_permlane16_swap.  permlane16_swap(vdst, src):
@@ -366,3 +248,118 @@ def sp_plan(FM: int, FN: int, NJA: int, NJB: int, RS: int = 2):
     b_slots = [2 + (b * (bend - 2)) // NJB for b in range(NJB)]
     return {"T": T, "X1": X1, "Y2": Y2, "a_slots": a_slots, "b_slots": b_slots,
             "NB1": sum(s < Y2 for s in b_slots)}
+
+
+# ---- family "q" (hgemm_kernel_sq.hpp): early-A operand split, two sync points per pipeline stage ---------------
+def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, rs64: int = 2):
+    """Mirror of CfgSQ / SqPlan: slot numbers of the leading reads, the sync point and the (DMA piece, trailing read)
+    items of interval A (phase 0) and interval B (phase 1)."""
+    NFA, NFB, T = FM * KT, FN * KT, FM * FN * KT
+    NJA, NJB = KT * PA, KT * PB
+    RS = rs64 if T >= 64 else 1
+    slack = slack64 if T >= 64 else (6 if T >= 32 else 2)
+    P, Q = RS * NFB + slack, RS * NFA + slack
+    STA = 2 if (T - P - 1) // (NJB + NFA) >= 2 else 1
+    STB = 2 if (T - Q - 1) // (NJA + NFB) >= 2 else 1
+
+    def interleave(first_n, second_n):     # item index of element i of the list that goes first / second
+        first = [2 * i if i < second_n else second_n + i for i in range(first_n)]
+        second = [2 * i + 1 if i < first_n else first_n + i for i in range(second_n)]
+        return first, second
+
+    a_piece_items, a_read_items = interleave(NJB, NFA)       # behind P: B pieces lead, A-fragment reads follow
+    b_read_items, b_piece_items = interleave(NFB, NJA)       # behind Q: B-fragment reads lead, A pieces follow
+    return {"T": T, "P": P, "Q": Q, "NJA": NJA, "NJB": NJB, "NFA": NFA, "NFB": NFB,
+            "lead_A": [RS * r for r in range(NFB)], "lead_B": [RS * r for r in range(NFA)],
+            "pieces_A": [P + 1 + STA * i for i in a_piece_items], "reads_A": [P + 1 + STA * i for i in a_read_items],
+            "reads_B": [Q + 1 + STB * i for i in b_read_items], "pieces_B": [Q + 1 + STB * i for i in b_piece_items]}
+
+
+def sq_schedule_hazards(plan: dict, steps: int = 8):
+    """Replay one wave's instruction stream of family q for `steps` pipeline stages and check every LDS hazard with
+    the kernel's own ordering rules.  Regions: ("A", s) / ("B", s) of stage s in {0, 1}.  Rules:
+      RAW  a fragment read of tile t from a region must come behind a sync point (counted vmcnt + barrier) whose wait
+           covers every DMA piece of tile t into that region.  s_waitcnt vmcnt(N) returns with at most the N YOUNGEST
+           pieces outstanding (they complete in order), so a piece is guaranteed to have landed iff at least N pieces
+           were issued after it before the sync;
+      WAR  a DMA piece into a region must come behind a sync point (lgkmcnt(0) + barrier) that follows every read of
+           the region's previous occupant (tile t-2).
+    All four waves run the same stream and leave a sync point together, so one stream is enough.  Returns a list of
+    violations (empty = the plan is hazard-free)."""
+    T, NJA, NJB = plan["T"], plan["NJA"], plan["NJB"]
+    events = []   # (time, kind, operand, tile); time = (interval index) * (T + 1) + slot, sync sorts before its slot's MFMA
+
+    def at(interval, slot, half=0):
+        return interval * 2 * (T + 2) + slot * 2 + half
+
+    # prologue: pieces of tiles 0, 1 (A then B each), sync, reads of tile 0 (A both halves, B first half), sync, A(2)
+    t0 = -10 * (T + 2)
+    order = 0
+    for tile in (0, 1):
+        for op, n in (("A", NJA), ("B", NJB)):
+            for _ in range(n):
+                events.append((t0 + order, "dma", op, tile)); order += 1
+    events.append((t0 + order, "sync_vm", NJA + NJB, None)); order += 1      # wait_vmcnt<NJA + NJB>: tile 0 landed
+    for op, half in (("A", 0), ("A", 1), ("B", 0)):
+        events.append((t0 + order, "read", op, (0, half))); order += 1
+    events.append((t0 + order, "sync_lgkm", None, None)); order += 1
+    for _ in range(NJA):
+        events.append((t0 + order, "dma", "A", 2)); order += 1
+    for t in range(steps):
+        ia, ib = 2 * t, 2 * t + 1
+        for s in plan["lead_A"]:
+            events.append((at(ia, s, 1), "read", "B", (t, 1)))
+        events.append((at(ia, plan["P"], 0), "sync_both", NJA + NJB, None))
+        for s in plan["pieces_A"]:
+            events.append((at(ia, s, 1), "dma", "B", t + 2))
+        for s in plan["reads_A"]:
+            events.append((at(ia, s, 1), "read", "A", (t + 1, 1)))
+        for s in plan["lead_B"]:
+            events.append((at(ib, s, 1), "read", "A", (t + 1, 0)))
+        events.append((at(ib, plan["Q"], 0), "sync_both", NJA + NJB, None))
+        for s in plan["reads_B"]:
+            events.append((at(ib, s, 1), "read", "B", (t + 1, 0)))
+        for s in plan["pieces_B"]:
+            events.append((at(ib, s, 1), "dma", "A", t + 3))
+    events.sort(key=lambda e: e[0])
+    bad = []
+    dmas = [e for e in events if e[1] == "dma"]
+    for time, kind, op, what in events:
+        if kind == "read":
+            tile = what[0]
+            mine = [e for e in dmas if e[2] == op and e[3] == tile]
+            last_piece = max(e[0] for e in mine)
+            # a sync with a vmcnt wait, between the last piece and this read, at which >= arg younger pieces were in the queue
+            ok = False
+            for st, sk, arg, _ in events:
+                if sk in ("sync_vm", "sync_both") and last_piece < st < time:
+                    younger = sum(1 for e in dmas if last_piece < e[0] < st)
+                    if younger >= arg:
+                        ok = True
+                        break
+            if not ok:
+                bad.append(("RAW", op, what, time))
+        if kind == "dma" and what >= 2:
+            prev_reads = [e for e in events if e[1] == "read" and e[2] == op and e[3][0] == what - 2]
+            if not prev_reads:
+                bad.append(("WAR: previous occupant was never read", op, what, time))
+                continue
+            last_read = max(e[0] for e in prev_reads)
+            if not any(sk in ("sync_lgkm", "sync_both") and last_read < st < time for st, sk, _, _ in events):
+                bad.append(("WAR", op, what, time))
+    return bad
+
+
+def fused_slab_offsets(threads: int, quads: int):
+    """Lane-order slab of the single-launch split-K (fused_off in hgemm_kernel.hpp): float index of element e of quad x
+    of thread tid.  Must be a bijection onto [0, quads * threads * 4) with 16-byte alignment per (x, tid)."""
+    return {(x, tid, e): (x * threads + tid) * 4 + e for x in range(quads) for tid in range(threads) for e in range(4)}
+
+
+def ragged_piece_width(addr: int, ld: int, K: int) -> int:
+    """piece_width() of hgemm_registry.hip: the widest power-of-two piece (halfs) that divides the row stride, K and the
+    base address alignment, so that a piece never straddles the end of a row."""
+    w = 8
+    while w > 1 and (ld % w or K % w or addr % (2 * w)):
+        w //= 2
+    return w

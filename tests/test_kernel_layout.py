@@ -85,29 +85,6 @@ def test_xcd_chunks_are_compact():
         assert len(rows) + len(cols) <= 12
 
 
-@pytest.mark.parametrize("geo", [(128, 128, 2, 4), (128, 256, 2, 4), (256, 128, 4, 2)])
-def test_pingpong_tile_matches_numpy_and_is_bank_conflict_free(geo):
-    rng = np.random.default_rng(1)
-    g = klm.GeometryPP(*geo)
-    M, N, K = g.BM + 24, g.BN + 4, 64
-    A = rng.integers(-3, 4, size=(M, K)).astype(np.float32)
-    Bt = rng.integers(-3, 4, size=(N, K)).astype(np.float32)
-    ref = A @ Bt.T
-    for (m0, n0) in [(0, 0), (g.BM, g.BN)]:
-        out, conflicts = klm.run_tile_pp(g, A, Bt, m0, n0)
-        assert conflicts == 0
-        rows, cols = range(m0, min(M, m0 + g.BM)), range(n0, min(N, n0 + g.BN))
-        assert len(out) == len(rows) * len(cols)
-        for m in rows:
-            for n in cols:
-                assert out[(m, n)] == ref[m, n], (m, n)
-
-
-@pytest.mark.parametrize("NU", [2, 3, 4, 5, 6, 8, 9, 32, 128])
-def test_pingpong_schedule_has_no_lds_hazard(NU):
-    assert klm.pp_schedule_hazards(NU) == []
-
-
 @pytest.mark.parametrize("fn", [2, 4, 8])
 def test_wide_epilogue_permlane_mapping(fn):
     cols = klm.wide_epilogue_columns(fn)
@@ -179,3 +156,52 @@ def test_sp_slot_plan_counts_match_the_waits(bm, bn):
     # Y1 wait: the A pieces of step+1 must have landed while B(step+1) and A(step+2) may fly: NJB + NJA younger
     # Y2 wait: B(step+1) landed while A(step+2) and the NB1 early B(step+2) pieces may fly
     assert NJA + NJB <= 63 and NJA + p["NB1"] <= 63          # vmcnt is a 6-bit counter
+
+
+@pytest.mark.parametrize("bm,bn,kt", [(256, 256, 1), (256, 128, 1), (128, 256, 1), (128, 128, 2), (128, 128, 1)])
+def test_family_q_schedule_has_no_lds_hazard(bm, bn, kt):
+    """Family q (hgemm_kernel_sq.hpp) orders its LDS traffic with TWO sync points per stage; the counted vmcnt and the
+    slot positions are replayed here for every instantiated geometry (the knob values of the experiment builds too)."""
+    nw, wm, wn = 4, 2, 2
+    FM, FN = bm // wm // 16, bn // wn // 16
+    PA, PB = bm // 8 // nw, bn // 8 // nw
+    for slack, rs in [(6, 2), (2, 2), (12, 2), (6, 1)]:
+        plan = klm.sq_plan(FM, FN, PA, PB, kt, slack, rs)
+        T = plan["T"]
+        slots = plan["pieces_A"] + plan["reads_A"]
+        assert len(set(slots)) == len(slots) and max(slots) < T and min(slots) > plan["P"]
+        slots = plan["pieces_B"] + plan["reads_B"]
+        assert len(set(slots)) == len(slots) and max(slots) < T and min(slots) > plan["Q"]
+        assert max(plan["lead_A"]) < plan["P"] and max(plan["lead_B"]) < plan["Q"]
+        assert plan["NJA"] + plan["NJB"] <= 63                      # vmcnt is a 6-bit counter
+        assert klm.sq_schedule_hazards(plan) == []
+
+
+def test_family_q_hazard_model_catches_a_misplaced_wait():
+    """The model must actually be able to fail: read the next tile's A fragments BEFORE sync P, or issue the A pieces
+    before sync Q, and a hazard is reported."""
+    plan = klm.sq_plan(8, 8, 8, 8)
+    early_read = dict(plan, reads_A=[plan["P"] - 1 - i for i in range(len(plan["reads_A"]))])
+    assert any(v[0] == "RAW" for v in klm.sq_schedule_hazards(early_read))
+    early_dma = dict(plan, pieces_B=[plan["Q"] - 1 - i for i in range(len(plan["pieces_B"]))])
+    assert any(v[0] == "WAR" for v in klm.sq_schedule_hazards(early_dma))
+
+
+def test_fused_split_k_slab_layout_is_a_bijection():
+    for threads, quads in [(256, 16), (256, 64), (512, 32), (64, 4)]:
+        offs = klm.fused_slab_offsets(threads, quads)
+        vals = sorted(offs.values())
+        assert vals == list(range(threads * quads * 4))             # BM*BN floats, each exactly once
+        assert all(offs[(x, t, 0)] % 4 == 0 for x in range(quads) for t in range(threads))   # 16-byte stores
+        # one store instruction of a wave = 64 consecutive threads of one quad = 1 KiB contiguous
+        assert all(offs[(0, t + 1, 0)] - offs[(0, t, 0)] == 4 for t in range(63))
+
+
+def test_ragged_loader_piece_width():
+    assert klm.ragged_piece_width(0, 200, 200) == 8 and klm.ragged_piece_width(0, 100, 100) == 4
+    assert klm.ragged_piece_width(0, 50, 50) == 2 and klm.ragged_piece_width(0, 40, 33) == 1
+    assert klm.ragged_piece_width(2, 64, 64) == 1 and klm.ragged_piece_width(8, 64, 64) == 4
+    for addr, ld, K in [(0, 200, 200), (4, 100, 100), (0, 66, 66), (16, 72, 40)]:
+        w = klm.ragged_piece_width(addr, ld, K)
+        # no piece straddles the end of a row, every piece is naturally aligned
+        assert K % w == 0 and ld % w == 0 and addr % (2 * w) == 0
