@@ -146,6 +146,24 @@ def device_time_us(fn, reps: int) -> float:
     return ts[len(ts) // 2]
 
 
+def isolated_time_us(fn, reps: int) -> float:
+    """Median device time of ONE call with the device idle before and after it (event, call, event, sync): the
+    device-side counterpart of the reference's per-call measurement, which syncs either side of every call
+    (benchmarking_utils.py:23-31).  device_time_us() above is the back-to-back (stream throughput) figure, where the
+    tail of one kernel overlaps the head of the next if both fit on a CU together."""
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def wall_time_us(fn, reps: int) -> float:
     """Reference-style timing (benchmarking_utils.py:23-31): sync, t0, call, sync, t1; mean."""
     tot = 0.0
@@ -201,12 +219,15 @@ def per_shape_report(lib, probs, stream) -> dict:
         for f in fns.values():
             settle(f, 0.15)
         rounds = {k: [] for k in fns}
+        iso = {k: [] for k in fns}
         for _ in range(3):
             for k, f in fns.items():
                 settle(f, 0.05)
                 rounds[k].append(device_time_us(f, reps))
+                iso[k].append(isolated_time_us(f, reps))
         for k, v in rounds.items():
-            row[k + "_us"] = sorted(v)[1]
+            row[k + "_us"] = sorted(v)[1]                       # back-to-back launches (stream throughput)
+            row[k + "_isolated_us"] = sorted(iso[k])[1]         # one call, device idle either side
         row["ours_wall_us"] = wall_time_us(ours, reps)
         lt = {k: row[k + "_us"] for k in fns if k.startswith("hipblaslt")}
         best_lt = min(lt, key=lt.get)
@@ -221,6 +242,7 @@ def per_shape_report(lib, probs, stream) -> dict:
             row["hipblaslt_auto_max_tflops"] = p.flops / auto * 1e-6
             row["speedup_vs_hipblaslt_auto_max"] = min(auto, heur) / row["ours_us"]   # strongest hipBLASLt variant
         row["speedup_wall_vs_hipblaslt_best"] = row["hipblaslt_best_wall_us"] / row["ours_wall_us"]
+        row["speedup_isolated_vs_hipblaslt_max"] = min(row[k + "_isolated_us"] for k in lt) / row["ours_isolated_us"]
         row["hipblaslt_compute16_fallback"] = bool(lib.hgemm_hipblaslt_compute16_fallback(0, 1) == 1)
         cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.hgemm_mi355x_plan(p.m, p.n, p.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))

@@ -26,8 +26,17 @@ namespace hgemm_mi355x {
 #define HGEMM_SQINST_1(BM, BN, WM, WN, KT) \
   template void launch_sq<CfgSQ<BM, BN, WM, WN, KT>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT) HGEMM_SQINST_##G(BM, BN, WM, WN, KT)
+#define HGEMM_RSINST_0(...)
+#define HGEMM_RSINST_1(...)
+#define HGEMM_RSINST_2(...)
+#define HGEMM_RSINST_3(...)
+#undef HGEMM_RSINST_1
+#define HGEMM_RSINST_1(BM, BN, BKS) \
+  template void launch_rs<CfgRS<BM, BN, BKS>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_RS(G, BM, BN, BKS) HGEMM_RSINST_##G(BM, BN, BKS)
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
+#undef HGEMM_RS
 }  // namespace hgemm_mi355x

@@ -40,6 +40,11 @@
 #ifndef HGEMM_SQ_RS64
 #define HGEMM_SQ_RS64 2       // leading reads every N slots when an interval has >= 64 slots
 #endif
+#ifndef HGEMM_SQ_XSTAGGER
+#define HGEMM_SQ_XSTAGGER 0   // 1: the workgroups of XCD x start every K walk at stage x * nk / 8 (and wrap around): the
+                              // XCDs stop reading the same K offsets at the same time, each XCD's workgroups stay in
+                              // lock-step (their L2 sharing of the A / B panels is untouched)
+#endif
 #ifndef HGEMM_SQ_QORDER
 #define HGEMM_SQ_QORDER 0     // behind Q: 0 = B-fragment reads lead the A pieces, 1 = the pieces lead
 #endif
@@ -193,8 +198,21 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       const int chunk_ = (lane & 7) ^ (((il_ & 1) << 2) | (lane >> 4));                                        \
       voff[j_] = ((uint32_t)min(r_, rmax_) * (uint32_t)ld_ + (uint32_t)chunk_ * 8u) * 2u;                      \
     }                                                                                                          \
-    cur[OP].kbyte = (uint32_t)nxt_kb;                                                                          \
+    {                                                                                                          \
+      const int s0_ = (HGEMM_SQ_XSTAGGER && nxt_nk >= 8) ? (int)(blockIdx.x % NUM_XCD) * (nxt_nk / NUM_XCD) : 0; \
+      cur[OP].kbyte = (uint32_t)nxt_kb + (uint32_t)s0_ * (CFG::KT * ROW_BYTES);                                \
+      cur[OP].wrap_kt = nxt_nk - s0_;   /* the walk wraps to the item's first stage when kt reaches this */   \
+    }                                                                                                          \
     cur[OP].item = (ITEM); cur[OP].kt = 0; cur[OP].nk = nxt_nk;                                                \
+  } while (0)
+
+// one stage on inside the current item (with the wrap of a staggered walk)
+#define SQ_STEP_CURSOR(OP)                                                                   \
+  do {                                                                                       \
+    ++cur[OP].kt;                                                                            \
+    cur[OP].kbyte += CFG::KT * ROW_BYTES;                                                    \
+    if (HGEMM_SQ_XSTAGGER && cur[OP].kt == cur[OP].wrap_kt)                                  \
+      cur[OP].kbyte -= (uint32_t)cur[OP].nk * (CFG::KT * ROW_BYTES);                         \
   } while (0)
 
 // Move a stream one K-step on; past the last step of the last item it stays put (the branch-free DMA then
@@ -202,8 +220,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
 #define SQ_ADVANCE(OP)                                        \
   do {                                                        \
     if (cur[OP].kt + 1 < cur[OP].nk) {                        \
-      ++cur[OP].kt;                                           \
-      cur[OP].kbyte += CFG::KT * ROW_BYTES;                   \
+      SQ_STEP_CURSOR(OP);                                     \
     } else if (cur[OP].item + 1 < walk.count) {               \
       SQ_LOAD_ITEM(OP, cur[OP].item + 1);                     \
     }                                                         \
@@ -254,7 +271,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   // ---- the two LDS-DMA streams (A: three tiles ahead of the MFMAs, B: two) ---------------------------------
   __amdgpu_buffer_rsrc_t rsA, rsB;
   uint32_t voff[NJ];
-  struct Cursor { uint32_t kbyte; int item, kt, nk; } cur[2];
+  struct Cursor { uint32_t kbyte; int item, kt, nk, wrap_kt; } cur[2];
   int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
   SQ_LOAD_ITEM(0, 0);
   SQ_LOAD_ITEM(1, 0);
@@ -302,9 +319,9 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma clang loop unroll(disable)
     for (; t + 5 < nk; t += 2) {
       SQ_K_STEP(fY, fZ);
-      cur[0].kbyte += CFG::KT * ROW_BYTES; ++cur[0].kt; cur[1].kbyte += CFG::KT * ROW_BYTES; ++cur[1].kt;
+      SQ_STEP_CURSOR(0); SQ_STEP_CURSOR(1);
       SQ_K_STEP(fZ, fY);
-      cur[0].kbyte += CFG::KT * ROW_BYTES; ++cur[0].kt; cur[1].kbyte += CFG::KT * ROW_BYTES; ++cur[1].kt;
+      SQ_STEP_CURSOR(0); SQ_STEP_CURSOR(1);
     }
     // last (up to) six K-steps: the streams may cross into the next work item
 #pragma clang loop unroll(disable)
@@ -369,6 +386,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 
 #undef SQ_LOAD_ITEM
 #undef SQ_ADVANCE
+#undef SQ_STEP_CURSOR
 #undef SQ_K_STEP
 #undef SQ_FRAG
 

@@ -1,5 +1,6 @@
 // Host-side launch thunks for the kernel instantiations listed in hgemm_configs.def.
 #pragma once
+#include "hgemm_kernel_rs.hpp"
 #include "hgemm_kernel_sq.hpp"
 
 #include <hip/hip_ext.h>
@@ -70,6 +71,16 @@ void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
     HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
   else
     HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
+}
+
+template <class CFG>
+void launch_rs(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
+    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
+  else
+    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_C16>), grid, CFG::THREADS, stream, ts, g);
 }
 
 struct KernelEntry {

@@ -12,10 +12,13 @@ namespace hgemm_mi355x {
   extern template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT) \
   extern template void launch_sq<CfgSQ<BM, BN, WM, WN, KT>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_RS(G, BM, BN, BKS) \
+  extern template void launch_rs<CfgRS<BM, BN, BKS>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
+#undef HGEMM_RS
 
 // The table holds host function pointers: keep it out of the device pass.
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -29,11 +32,14 @@ thread_local LaunchTiming t_launch_timing;
    Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true, 64},
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT)
+#define HGEMM_RS(G, BM, BN, BKS)
 const KernelEntry g_kernel_table[] = {
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
+#undef HGEMM_RS
+#define HGEMM_RS(G, BM, BN, BKS)
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
 // MI = 16 members keep their round-1 names (tuned tables refer to plans by name); MI = 32 members add "_m32"
 #define HGEMM_SP_NAME_16(BM, BN, WM, WN) "s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
@@ -49,10 +55,22 @@ const KernelEntry g_kernel_table[] = {
    CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT>>,                          \
    256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64)), true, 64 * KT},
 #include "hgemm_configs.def"
+#undef HGEMM_CFG
+#undef HGEMM_SP
+#undef HGEMM_SQ
+#undef HGEMM_RS
+#define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
+#define HGEMM_SP(G, BM, BN, WM, WN, MI)
+#define HGEMM_SQ(G, BM, BN, WM, WN, KT)
+#define HGEMM_RS(G, BM, BN, BKS)                                                                            \
+  {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS), BM, BN, 2, 2, 16, 1, CfgRS<BM, BN, BKS>::THREADS,  \
+   CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS},
+#include "hgemm_configs.def"
 };
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
+#undef HGEMM_RS
 const int g_num_kernels = (int)(sizeof(g_kernel_table) / sizeof(g_kernel_table[0]));
 #endif  // !__HIP_DEVICE_COMPILE__
 

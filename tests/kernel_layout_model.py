@@ -363,3 +363,47 @@ def ragged_piece_width(addr: int, ld: int, K: int) -> int:
     while w > 1 and (ld % w or K % w or addr % (2 * w)):
         w //= 2
     return w
+
+
+# ---- family "r" (hgemm_kernel_rs.hpp): LDS image [rows][BKS*2 B], chunk c of row r at slot c ^ (r & 15) ----------------
+def rs_write_addrs(bks: int, threads: int = 256, p: int = 0):
+    """ds_write_b128 byte addresses of chunk p of every thread of one wave-sized slice (the kernel's lds_of(p))."""
+    rb, nch = bks * 2, bks * 2 // 16
+    rp = threads // nch
+    out = []
+    for tid in range(threads):
+        r0, c0 = tid // nch, tid % nch
+        base = r0 * rb + ((c0 ^ (r0 & 15)) << 4)
+        addr = (base ^ (128 if (rp == 8 and (p & 1)) else 0)) + p * rp * rb
+        row = r0 + p * rp
+        assert addr == row * rb + ((c0 ^ (row & 15)) << 4)        # the XOR-constant form equals the definition
+        out.append((row, c0, addr))
+    return out
+
+
+def rs_write_conflicts(addrs) -> int:
+    """ds_write_b128: contiguous 8-lane groups, 32 banks of 4 B (MI355X_MICROARCH.md LDS table)."""
+    extra = 0
+    for w in range(0, len(addrs), 64):
+        for g0 in range(w, w + 64, 8):
+            per_bank = {}
+            for lane in range(g0, g0 + 8):
+                a = addrs[lane][2]
+                for dw in range(4):
+                    per_bank.setdefault(((a // 4) + dw) % 32, set()).add((a // 4) + dw)
+            extra += max(len(v) for v in per_bank.values()) - 1
+    return extra
+
+
+def rs_frag_read_addrs(bks: int, ks: int, i: int = 0):
+    """ds_read_b128 addresses of one wave for fragment row block i, K slice ks: frag_lane ^ (ks << 6) + i*16*RB."""
+    rb = bks * 2
+    out = []
+    for lane in range(64):
+        l15, lq = lane & 15, lane >> 4
+        frag_lane = l15 * rb + ((lq ^ l15) << 4)
+        addr = (frag_lane ^ (ks << 6)) + i * 16 * rb
+        row, chunk = i * 16 + l15, 4 * ks + lq
+        assert addr == row * rb + ((chunk ^ (row & 15)) << 4)     # = where rs_write_addrs put (row, chunk)
+        out.append(addr)
+    return out

@@ -432,6 +432,9 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("s256x256_w2x2_m32", 1, (1024, 1536, 2048)),      # SP, 32x32x16 MFMA
         ("s256x256_w2x2_m32", 1, (4608, 4608, 512)),       # persistent with several items per workgroup
         ("s256x128_w2x2", 1, (4352, 4352, 1024)),          # hybrid tail (34 x 34 tiles)
+        ("r64x64_k256", 1, (2048, 64, 8192)),              # register-staged streaming kernel, K stagger
+        ("r128x64_k128", 2 | 0x10000, (4100, 64, 4096)),   # ... ragged M edge (out-of-range rows read as zeros), fused split-K
+        ("r64x128_k128", 4, (192, 4000, 2048)),            # ... ragged N edge, two-pass split-K
         ("q128x128_w2x2_k128", 1, (1024, 4096, 4096)),     # BK=128 stages, one tile per CU
         ("q128x128_w2x2_k128", 1, (2304, 2304, 640)),      # ... several items per workgroup, odd stage count (5)
         ("q128x128_w2x2", 2 | 0x10000, (1152, 1152, 4096)),# BK=64, two workgroups per CU, single-launch split-K

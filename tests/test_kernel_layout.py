@@ -205,3 +205,25 @@ def test_ragged_loader_piece_width():
         w = klm.ragged_piece_width(addr, ld, K)
         # no piece straddles the end of a row, every piece is naturally aligned
         assert K % w == 0 and ld % w == 0 and addr % (2 * w) == 0
+
+
+@pytest.mark.parametrize("bks", [128, 256])
+def test_family_r_lds_image_is_consistent_and_conflict_free(bks):
+    """Register-staged streaming family: every (row, chunk) written once, read back from the same address, no bank
+    conflicts for the 8-lane ds_write_b128 groups nor for the 16-lane ds_read_b128 groups."""
+    nch = bks * 2 // 16
+    rows = 128                                   # BM + BN of the 64 x 64 tile
+    seen = {}
+    for p in range(rows * nch // 256):
+        addrs = klm.rs_write_addrs(bks, 256, p)
+        assert klm.rs_write_conflicts(addrs) == 0
+        for row, c, a in addrs:
+            assert (row, c) not in seen
+            seen[(row, c)] = a
+    assert len(seen) == rows * nch and len(set(seen.values())) == len(seen)
+    for ks in range(bks // 32):
+        for i in range(2):
+            reads = klm.rs_frag_read_addrs(bks, ks, i)
+            assert klm.bank_conflict_extra_cycles(reads) == 0
+            for lane, a in enumerate(reads):
+                assert seen[(i * 16 + (lane & 15), 4 * ks + (lane >> 4))] == a
