@@ -147,9 +147,14 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   // geomean regret of the model's pick against the measured best 2.0 % (3.9 % before the fit).
   // MFMA efficiency falls with the wave tile's operand reuse (LDS bytes per flop); the software-
   // pipelined family ('s', one wave per SIMD) sustains ~1.5x the classic schedule's rate.
-  const char family = e.name[0] == 'q' ? 's' : e.name[0];   // 'q' = 's' with the early-A split
+  // Round 2 (families q, r added; tuning/r02_grid_tune_run{A,B}, r02_skinny_tune_run1): the 128x128 members of
+  // family q sustain the classic rate per flop (their gain is the pipelining, modelled by step_lat), and q beats
+  // s by a few percent once a work item has >= 16 K-steps, s wins below (one coordinate computation per item).
+  // Regret of the model's pick among the measured candidates, ties broken in table order: 5.5 % (6.8 % before).
+  const bool is_q = e.name[0] == 'q', is_q128 = is_q && e.bm == 128 && e.bn == 128;
+  const char family = is_q ? 's' : e.name[0];   // 'q' = 's' with the early-A split
   const double reuse = (double)tm * tn / (tm + tn);
-  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (family == 's' ? 1.47 : family == 'p' ? 1.12 : 1.0);
+  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (is_q128 ? 1.0 : family == 's' ? 1.47 : 1.0);
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
   // per-K-step latency floor: barrier + LDS-DMA round trip (double-buffered rings expose all of it)
   const double step_lat = family == 's' ? 0.40 : (e.nbuf >= 3 ? 0.33 : 0.74);
@@ -160,8 +165,13 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
     bytes += 8.0 * (double)M * N * splits;
     extra = kBoundaryUs + 4.0 * (double)M * N * (splits + 0.5) / kHbmBytesUs + 0.17 * splits;
   }
-  return kLaunchUs + std::max(main_us, bytes / kHbmBytesUs) + extra;
+  const double q_bias = (is_q && !is_q128) ? (K / splits >= 1024 ? 0.99 : 1.01) : 1.0;
+  return (kLaunchUs + std::max(main_us, bytes / kHbmBytesUs) + extra) * q_bias;
 }
+
+// K the geometry accepts: a multiple of its stage depth, or any multiple of 8 for the families that zero-fill a
+// partial last K-step themselves
+inline bool k_ok(const KernelEntry& e, int K) { return K % e.kgran == 0 || (e.ktail && K % 8 == 0); }
 
 void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   double best = 1e30;
@@ -172,7 +182,7 @@ void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     // Do not pick tiles that mostly compute padding.
     if (e.bm > M * 2 && e.bm > 32) continue;
     if (e.bn > N * 2 && e.bn > 32) continue;
-    if (K % e.kgran != 0) continue;
+    if (!k_ok(e, K)) continue;
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && ksteps / s < 4) break;
       const double t = model_us(e, M, N, K, s);
@@ -184,9 +194,10 @@ void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
 }
 
+// alignment rules of the LDS-DMA path (the K multiple depends on the geometry: k_ok())
 bool mfma_path_ok(const void* a, const void* bt, const void* c, int M, int N, int K, int lda,
                   int ldb, int ldc) {
-  if (K % BK != 0 || (N & 3) != 0) return false;
+  if (K % 8 != 0 || (N & 3) != 0) return false;
   if ((lda & 7) || (ldb & 7) || (ldc & 3)) return false;
   if (((uintptr_t)a & 15) || ((uintptr_t)bt & 15) || ((uintptr_t)c & 7)) return false;
   (void)M;
@@ -221,7 +232,8 @@ int hgemm_mi355x_config_info(int id, int out[8]) {
 }
 
 int hgemm_mi355x_config_k_granularity(int id) {
-  return (id >= 0 && id < g_num_kernels) ? g_kernel_table[id].kgran : 1;
+  if (id < 0 || id >= g_num_kernels) return 1;
+  return g_kernel_table[id].ktail ? 8 : g_kernel_table[id].kgran;
 }
 
 int hgemm_mi355x_config_by_name(const char* name) {
@@ -242,7 +254,7 @@ int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* gro
     *config_id = lo->cfg; *splits = lo->splits; *group_m = lo->group_m;
     return HGEMM_OK;
   }
-  if (K % BK != 0 || (N & 3) != 0) {  // register-staged any-shape MFMA kernel (hgemm_kernel_rg.hpp)
+  if (K % 8 != 0 || (N & 3) != 0) {  // register-staged any-shape MFMA kernel (hgemm_kernel_rg.hpp)
     *config_id = HGEMM_CONFIG_RAGGED; *splits = 1; *group_m = 1;
     return HGEMM_OK;
   }
@@ -317,8 +329,9 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     // 32-bit LDS-DMA offsets: (BM-1) rows * ld * 2 B + K * 2 B must stay below 4 GiB; beyond that the
     // register-staged kernel (64-bit addressing) takes over instead of an error.
     const KernelEntry& e = g_kernel_table[config_id];
-    if ((double)e.bm * lda * 2.0 + K * 2.0 >= 4294967296.0 || (double)e.bn * ldb * 2.0 + K * 2.0 >= 4294967296.0)
-      fast = false;
+    const double reach = e.ktail ? 2147483648.0 : 4294967296.0;   // (the classic family keeps bit 31 as its out-of-range mark)
+    if ((double)e.bm * lda * 2.0 + K * 2.0 >= reach || (double)e.bn * ldb * 2.0 + K * 2.0 >= reach) fast = false;
+    if (K % BK != 0 && !e.ktail) fast = false;   // a partial last K-step on a geometry that cannot pad it: any-shape kernel
   }
   if (!fast) {
     if (config_id != HGEMM_CONFIG_GENERIC && b_col_major) {
@@ -334,9 +347,9 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     g.tiles_n = (N + e.bn - 1) / e.bn;
     const long tiles = (long)g.tiles_m * g.tiles_n;
     // pipeline stages of this geometry along K (BK = 64, or 128 for the "_k128" members)
-    if (K % e.kgran != 0) return HGEMM_ERR_BAD_ARG;
+    if (!k_ok(e, K)) return HGEMM_ERR_BAD_ARG;
     const int kgran = e.kgran;
-    const int ksteps = K / kgran;
+    const int ksteps = (K + kgran - 1) / kgran;
     splits = std::max(1, std::min(splits, ksteps));
     const int steps_per_split = (ksteps + splits - 1) / splits;
     splits = (ksteps + steps_per_split - 1) / steps_per_split;  // no empty split

@@ -165,7 +165,7 @@ __device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int
   tc.m0 = (first_m + tin % gm) * BM;
   tc.n0 = (tin / gm) * BN;
   tc.k_begin = split * g.k_chunk;
-  tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin) / BK;
+  tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin + BK - 1) / BK;   // the last K-step may be partial (classic family)
   if (HGEMM_DBG(g, 4)) tc.nk = min(tc.nk, 2);
   if (g.tail_tiles > 0 || g.counters != nullptr) {   // compact per-item slabs (tail pass, fused split-K)
     tc.slab = g.partial + (size_t)bid * ((size_t)BM * BN);
@@ -358,6 +358,28 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsA, __amdgpu_
   }
 }
 
+// The last, PARTIAL K-step of a work item (K % 64 != 0, K % 8 == 0): lanes whose 16-byte source chunk lies at
+// k >= K get bit 31 set in their offset, which is beyond the descriptors' 2 GiB range: the load returns zeros, so
+// the tail of every LDS row is zero-filled by the DMA itself (the reference pads K in the harness instead,
+// tools/utils.py:8-36).  Bit j of tailmask = piece j of this lane is past K.
+template <class CFG>
+__device__ __forceinline__ void stage_tile_tail(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
+                                                const uint32_t (&voff)[CFG::NJ], uint32_t tailmask, char* lds_stage,
+                                                int wave, uint32_t kbyte) {
+#pragma unroll
+  for (int j = 0; j < CFG::NJ; ++j) {
+    const int i = wave + j * CFG::NW;
+    if (CFG::NI % CFG::NW == 0 || i < CFG::NI) {
+      lds_void_t* dst = (lds_void_t*)(lds_stage + i * 1024);
+      const uint32_t vo = voff[j] | (((tailmask >> j) & 1u) << 31);
+      if (i < CFG::NI_A)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, vo, kbyte, 0, HGEMM_DMA_AUX);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, vo, kbyte, 0, HGEMM_DMA_AUX);
+    }
+  }
+}
+
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <class CFG, int EPI>
@@ -382,10 +404,15 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
   // clamped to the last valid row (their products are never stored).
   const f16* a_base = g.A + (size_t)m0 * g.lda;
   const f16* b_base = g.Bt + (size_t)n0 * g.ldb;
+  // (range 2 GiB: every real offset is below it -- host check -- and bit 31 marks a lane as out of range)
   __amdgpu_buffer_rsrc_t rsA =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0xFFFFFFFFu, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x80000000u, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB =
-      __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0xFFFFFFFFu, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x80000000u, 0x00020000);
+  // valid 16-byte chunks of the last K-step of this work item (8 = it is a full step)
+  const int k_items = min(g.K, k_begin + g.k_chunk) - k_begin;
+  const int tail_chunks = (k_items % BK) ? (k_items % BK) / 8 : 8;
+  uint32_t tailmask = 0;
 
   uint32_t voff[NJ];
 #pragma unroll
@@ -400,6 +427,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
     // LDS slot (lane & 7) of row r holds source chunk slot ^ ((r >> 1) & 7); r & 15 = (il&1)*8 + lane>>3
     const int chunk = (lane & 7) ^ (((il & 1) << 2) | (lane >> 4));
     voff[j] = ((uint32_t)rc * (uint32_t)ld + (uint32_t)chunk * 8u) * 2u;
+    tailmask |= (chunk >= tail_chunks ? 1u : 0u) << j;
   }
 
   // ---- fragment read offsets (bytes inside a stage) -----------------------------------------
@@ -432,7 +460,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
 #pragma unroll
   for (int s = 0; s < NBUF - 1; ++s) {
     if (s < nk) {
-      stage_tile<CFG>(rsA, rsB, voff, smem + s * CFG::STAGE_BYTES, wave, kbyte);
+      if (s == nk - 1 && tail_chunks < 8) stage_tile_tail<CFG>(rsA, rsB, voff, tailmask, smem + s * CFG::STAGE_BYTES, wave, kbyte);
+      else stage_tile<CFG>(rsA, rsB, voff, smem + s * CFG::STAGE_BYTES, wave, kbyte);
       kbyte += ROW_BYTES;
     }
   }
@@ -448,7 +477,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
     __builtin_amdgcn_s_barrier();   // all waves' pieces of tile t landed; stage `wr` is free again
 
     if (t + NBUF - 1 < nk && !HGEMM_DBG(g, 1)) {
-      stage_tile<CFG>(rsA, rsB, voff, smem + wr * CFG::STAGE_BYTES, wave, kbyte);
+      if (t + NBUF == nk && tail_chunks < 8) stage_tile_tail<CFG>(rsA, rsB, voff, tailmask, smem + wr * CFG::STAGE_BYTES, wave, kbyte);
+      else stage_tile<CFG>(rsA, rsB, voff, smem + wr * CFG::STAGE_BYTES, wave, kbyte);
       kbyte += ROW_BYTES;
     }
 

@@ -90,8 +90,9 @@ struct KernelEntry {
   void (*launch)(const GemmArgs&, int, hipStream_t, int, TimingSlot);
   int persistent_wgs;  // > 0: the kernel walks its work items itself, launch at most this many workgroups
   bool has_fused;      // the family has a single-launch split-K epilogue (EPI_FUSED)
-  int kgran;           // K granularity of one pipeline stage (64, or 128 for the BK=128 members): K and every
-                       // split-K chunk must be a multiple
+  int kgran;           // K granularity of one pipeline stage (64, or 128 / 256 for the deep-stage members): every
+                       // split-K chunk is a multiple, and so is K unless `ktail`
+  bool ktail;          // the kernel zero-fills a partial last K-step by itself: any K % 8 == 0 is accepted
 };
 
 extern const KernelEntry g_kernel_table[];

@@ -29,7 +29,7 @@ thread_local LaunchTiming t_launch_timing;
   {"t" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m" HGEMM_STR(MI)  \
    "_s" HGEMM_STR(NB),                                                                         \
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
-   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true, 64},
+   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true, 64, true},
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT)
 #define HGEMM_RS(G, BM, BN, BKS)
@@ -47,13 +47,13 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)                                                          \
   {HGEMM_SP_NAME_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2,                                      \
    CfgSP<BM, BN, WM, WN, MI>::THREADS, CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64,                  \
-   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64)), true, 64},
+   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64)), true, 64, false},
 #define HGEMM_SQ_NAME_1(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
 #define HGEMM_SQ_NAME_2(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_k128"
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT)                                                                     \
   {HGEMM_SQ_NAME_##KT(BM, BN, WM, WN), BM, BN, WM, WN, 16, 2, CfgSQ<BM, BN, WM, WN, KT>::THREADS,              \
    CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT>>,                          \
-   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64)), true, 64 * KT},
+   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64)), true, 64 * KT, false},
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
@@ -64,7 +64,7 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT)
 #define HGEMM_RS(G, BM, BN, BKS)                                                                            \
   {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS), BM, BN, 2, 2, 16, 1, CfgRS<BM, BN, BKS>::THREADS,  \
-   CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS},
+   CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS, false},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG

@@ -66,7 +66,7 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * (reference kernels/a100_F32F16F16F32/64_4096_64.cu:275-287) and cuda_l2_<dev>_fp16
  * (kernels/a100_F16F16F16F16/4096_4096_4096.cu:280-295).  Picks the tuned kernel geometry /
  * split-K plan for (M,N,K) (tuned table first, analytic model otherwise) and launches it.
- * Any M,N,K >= 1 is accepted; shapes the LDS-DMA kernels cannot take (K % 64 != 0, N % 4 != 0,
+ * Any M,N,K >= 1 is accepted; shapes the LDS-DMA kernels cannot take (K % 8 != 0, N % 4 != 0,
  * pointers or strides not 16-byte aligned, operands beyond 32-bit tile offsets) run on a register-staged
  * MFMA kernel that pads on the way into LDS (the reference pads in the harness, tools/utils.py:8-36).
  * Thread / stream safety: calls may be issued from any thread on any stream and device; split-K plans use
@@ -106,9 +106,10 @@ const char* hgemm_mi355x_config_name(int config_id);
 /* out[0..7] = BM, BN, WM, WN, MI, NBUF, threads, lds_bytes */
 int hgemm_mi355x_config_info(int config_id, int out[8]);
 int hgemm_mi355x_config_by_name(const char* name);
-/* K granularity of a geometry's pipeline stage (64, or 128 for the "_k128" members): hgemm_mi355x_launch
- * returns HGEMM_ERR_BAD_ARG for a table geometry when K is not a multiple (the planner never picks one);
- * 1 for the special ids. */
+/* The K multiple a geometry accepts: 8 for the classic "t" family (it zero-fills a partial last K-step itself), the
+ * pipeline stage depth for the others (64; 128 / 256 for the "_k128" / "_k256" members).  hgemm_mi355x_launch
+ * returns HGEMM_ERR_BAD_ARG for a table geometry when K is not a multiple (the planner never picks one); 1 for
+ * the special ids. */
 int hgemm_mi355x_config_k_granularity(int config_id);
 
 /* Split-K workspace.  Default: the library keeps one private device buffer per (device, stream) pair that

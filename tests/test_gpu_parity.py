@@ -324,6 +324,27 @@ def test_ragged_kernel_and_reference_kernel_explicitly(g, oracle, shape):
     assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
 
 
+@pytest.mark.parametrize("shape", [(1000, 520, 200), (320, 448, 520), (200, 136, 1000), (4000, 520, 4008), (257, 1028, 72), (64, 64, 8)])
+def test_partial_last_k_step_of_the_classic_family(g, oracle, shape):
+    """K % 64 != 0, K % 8 == 0: the classic geometries zero-fill the partial last K-step through out-of-range DMA
+    lanes.  Every classic geometry x split-K form, plus the library's own plan, bit-exact; guard: NaN-prefilled C."""
+    m, n, k = shape
+    rng = np.random.default_rng(m + 3 * n + 5 * k)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a, b)
+    for entry in ("fp32", "fp16"):
+        assert np.array_equal(g.gemm(a, b, entry).view(np.uint16), truth.view(np.uint16)), entry
+    for cid, name in enumerate(g.config_names()):
+        if not name.startswith("t"):
+            continue
+        for splits in (1, 3, 2 | 0x10000):
+            got = g.gemm(a, b, plan=(cid, splits, 2))
+            assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, splits)
+    # operands that end exactly at the end of their allocation: the partial step must not read past it harmfully
+    a_t = torch.from_numpy(a).cuda().clone()
+    assert np.array_equal(g.gemm(a_t.cpu().numpy(), b).view(np.uint16), truth.view(np.uint16))
+
+
 def test_ragged_kernel_randn_tolerance(g, oracle):
     m, n, k = 1000, 520, 200
     rng = np.random.default_rng(12)

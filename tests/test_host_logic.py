@@ -89,8 +89,14 @@ def test_planner_routes_ragged_shapes_to_the_register_staged_mfma_kernel(lib):
     cfg, splits, group = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.hgemm_mi355x_plan(100, 30, 50, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert cfg.value == -2 and splits.value == 1      # HGEMM_CONFIG_RAGGED (K % 64 != 0, N % 4 != 0)
-    assert lib.hgemm_mi355x_plan(1000, 520, 200, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
+    assert lib.hgemm_mi355x_plan(65, 30, 100, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert cfg.value == -2
+    # K % 64 != 0 but K % 8 == 0: a classic ("t") geometry, which zero-fills its partial last K-step by itself
+    assert lib.hgemm_mi355x_plan(1000, 520, 200, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
+    assert cfg.value >= 0 and lib.hgemm_mi355x_config_name(cfg.value).decode().startswith("t")
+    assert lib.hgemm_mi355x_config_k_granularity(cfg.value) == 8
+    assert lib.hgemm_mi355x_plan(4000, 4000, 4000, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
+    assert cfg.value >= 0 and lib.hgemm_mi355x_config_name(cfg.value).decode().startswith("t")
     assert lib.hgemm_mi355x_plan(1000, 520, 192, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert cfg.value >= 0                              # aligned: an LDS-DMA geometry
     assert lib.hgemm_mi355x_plan(0, 4, 4, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == -1
