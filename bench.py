@@ -23,7 +23,7 @@ Extra objects on the JSON line:
                 rank 0 at N=1 over a bounded sample of the same shape
   shapes        BASELINE.json's three single-GPU shapes: device-timed TFLOP/s of ours, hipBLASLt heuristic AND
                 autotune (tn, nn), rocBLAS; the reference-style host wall-clock (sync either side of each call);
-                a roofline entry per shape
+                our per-call time inside a 32-launch hipGraph replay; a roofline entry per shape
 """
 from __future__ import annotations
 
@@ -176,6 +176,41 @@ def wall_time_us(fn, reps: int) -> float:
     return tot / reps * 1e6
 
 
+GRAPH_LAUNCHES = 32
+
+
+def graph_time_us(lib, p, reps: int = 7) -> dict:
+    """Per-call time of OUR entry point inside a hipGraph of GRAPH_LAUNCHES back-to-back calls (rotating operand
+    sets): device time between events around one replay, and the reference-style host wall-clock (sync, t0,
+    replay, sync), both divided by the launches in the graph.  What a serving loop that captures its GEMM calls
+    pays per call; for the launch-bound 64x4096x64 this is where the ~7 us host launch path goes away."""
+    lib.hgemm_mi355x_reserve_workspace.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    s = torch.cuda.Stream()
+    check(lib, lib.hgemm_mi355x_reserve_workspace(p.m, p.n, p.k, s.cuda_stream), "reserve_workspace")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        for _ in range(GRAPH_LAUNCHES):
+            launch_ours(lib, p, torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    dev, wall = [], []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        wall.append((time.time() - t0) * 1e6 / GRAPH_LAUNCHES)
+        dev.append(e0.elapsed_time(e1) * 1e3 / GRAPH_LAUNCHES)
+    del graph
+    return {"ours_graph_us": sorted(dev)[len(dev) // 2], "ours_graph_wall_us": sorted(wall)[len(wall) // 2],
+            "graph_launches": GRAPH_LAUNCHES}
+
+
 def roofline_entry(p, us: float, traffic=None) -> dict:
     """Which roof bounds the shape (arithmetic intensity vs the ridge 2.5 PF / 8 TB/s = 312 flop/B) and how close
     the measured launch is.  Algorithmic work: 2MNK flop; 2(MK + KN + MN) bytes (A, B read once, C written once)."""
@@ -242,6 +277,10 @@ def per_shape_report(lib, probs, stream) -> dict:
             row["hipblaslt_auto_max_tflops"] = p.flops / auto * 1e-6
             row["speedup_vs_hipblaslt_auto_max"] = min(auto, heur) / row["ours_us"]   # strongest hipBLASLt variant
         row["speedup_wall_vs_hipblaslt_best"] = row["hipblaslt_best_wall_us"] / row["ours_wall_us"]
+        try:
+            row.update(graph_time_us(lib, p))
+        except RuntimeError as e:   # reported, never fatal: the headline number does not depend on it
+            row["ours_graph_error"] = str(e)[:200]
         row["speedup_isolated_vs_hipblaslt_max"] = min(row[k + "_isolated_us"] for k in lt) / row["ours_isolated_us"]
         row["hipblaslt_compute16_fallback"] = bool(lib.hgemm_hipblaslt_compute16_fallback(0, 1) == 1)
         cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

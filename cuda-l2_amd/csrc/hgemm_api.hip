@@ -26,14 +26,21 @@ int g_debug_flags = 0;  // tuner-only build: hgemm_mi355x_set_debug
 // arrival counters.  Layout: [kCounterBytes of tile arrival counters, zero between launches][fp32 slabs].
 // Growth happens on first use of a bigger plan only (hipFree of the old buffer synchronises the device,
 // so no kernel can still be using it); steady state is a mutex + a short linear search.
+// hipGraph capture: a captured launch bakes the workspace address into its kernel node, so (i) nothing is
+// allocated while the stream is capturing (a plan that does not fit what is there degrades to splits = 1,
+// like a lent buffer that is too small; hgemm_mi355x_reserve_workspace sizes it beforehand) and (ii) a buffer
+// that a capture has seen is never freed by growth: it is retired and lives until
+// hgemm_mi355x_release_workspaces, so graphs instantiated earlier stay valid.
 constexpr size_t kCounterBytes = (size_t)256 << 10;             // 65536 tiles
 constexpr size_t kMaxFusedTiles = kCounterBytes / sizeof(unsigned);
 struct Workspace {
   int device; hipStream_t stream;
   char* ptr; size_t bytes;      // whole allocation (counters + slabs)
+  bool captured;                // some hipGraph holds ptr
 };
 std::mutex g_ws_mutex;
 std::vector<Workspace> g_ws;
+std::vector<void*> g_ws_retired;   // buffers replaced by growth while a graph may still reference them
 // caller-lent buffer (hgemm_mi355x_set_workspace): used for every stream of the device that was current
 // when it was lent; the caller promises not to run GEMMs concurrently on several streams then.
 char*  g_lent_ptr = nullptr;
@@ -58,11 +65,21 @@ int ensure_workspace(size_t slab_bytes, hipStream_t stream, float** slabs, unsig
   for (Workspace& e : g_ws)
     if (e.device == dev && e.stream == stream) { w = &e; break; }
   if (!w) {
-    g_ws.push_back({dev, stream, nullptr, 0});
+    g_ws.push_back({dev, stream, nullptr, 0, false});
     w = &g_ws.back();
   }
+  // (the legacy default stream cannot capture, and querying it while another stream captures is an error)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+  if (capturing) {
+    if (need > w->bytes) return HGEMM_ERR_NO_WORKSPACE_INTERNAL;
+    w->captured = true;
+  }
   if (need > w->bytes) {
-    if (w->ptr) {
+    if (w->ptr && w->captured) {
+      g_ws_retired.push_back(w->ptr);
+      w->ptr = nullptr; w->bytes = 0; w->captured = false;
+    } else if (w->ptr) {
       hipError_t e = hipFree(w->ptr);   // device-synchronising: nothing in flight still reads the old slabs
       if (e != hipSuccess) { g_last_hip_error = (int)e; return HGEMM_ERR_HIP; }
       w->ptr = nullptr; w->bytes = 0;
@@ -299,8 +316,24 @@ int hgemm_mi355x_release_workspaces(void) {
   int rc = HGEMM_OK;
   for (Workspace& w : g_ws)
     if (w.ptr && hipFree(w.ptr) != hipSuccess) rc = HGEMM_ERR_HIP;
+  for (void* p : g_ws_retired)
+    if (hipFree(p) != hipSuccess) rc = HGEMM_ERR_HIP;
   g_ws.clear();
+  g_ws_retired.clear();
   return rc;
+}
+
+int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
+  int cfg = 0, splits = 1, group = 1;
+  const int st = hgemm_mi355x_plan(M, N, K, &cfg, &splits, &group);
+  if (st != HGEMM_OK) return st;
+  // split-K slabs of the plan, or the hybrid tail's compact slabs (one 256x256 fp32 tile per resident workgroup at most)
+  size_t slab = hgemm_mi355x_workspace_bytes(M, N, splits);
+  slab = std::max(slab, kCounterBytes + (size_t)256 * 256 * 256 * sizeof(float)) - kCounterBytes;
+  float* slabs = nullptr; unsigned* counters = nullptr;
+  const int rc = ensure_workspace(slab, (hipStream_t)stream, &slabs, &counters);
+  return rc == HGEMM_ERR_NO_WORKSPACE_INTERNAL ? HGEMM_ERR_NO_WORKSPACE : rc;
 }
 
 int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* a, const void* b,
@@ -449,6 +482,7 @@ const char* hgemm_mi355x_strerror(int status) {
     case HGEMM_ERR_BACKEND: return "rocBLAS/hipBLASLt error";
     case HGEMM_ERR_NOT_READY: return "baseline not initialised / no algorithm selected";
     case HGEMM_ERR_NO_ALGO: return "hipBLASLt returned no usable algorithm";
+    case HGEMM_ERR_NO_WORKSPACE: return "no split-K workspace (lent buffer too small, out of memory, or stream capturing)";
     default: return "unknown status";
   }
 }

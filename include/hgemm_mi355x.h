@@ -38,7 +38,9 @@ typedef enum {
   HGEMM_ERR_HIP = -3,         /* a HIP runtime call failed (see hgemm_mi355x_last_hip_error) */
   HGEMM_ERR_BACKEND = -4,     /* rocBLAS / hipBLASLt returned an error */
   HGEMM_ERR_NOT_READY = -5,   /* baseline used before its init / find_best call */
-  HGEMM_ERR_NO_ALGO = -6      /* hipBLASLt returned no usable algorithm */
+  HGEMM_ERR_NO_ALGO = -6,     /* hipBLASLt returned no usable algorithm */
+  HGEMM_ERR_NO_WORKSPACE = -7 /* hgemm_mi355x_reserve_workspace only: lent buffer too small, out of memory, or the
+                                 stream is capturing (a GEMM call never returns it: it runs without split-K instead) */
 } hgemm_status_t;
 
 /* Accumulate mode names the reference's two kernel trees (F32F16F16F32 / F16F16F16F16).
@@ -121,9 +123,19 @@ int hgemm_mi355x_config_k_granularity(int config_id);
  * must not run split-K GEMMs concurrently on several streams while it is lent -- and its first 256 KiB are
  * zeroed here (tile arrival counters).  A plan that does not fit the lent buffer runs with splits = 1.
  * hgemm_mi355x_workspace_bytes gives a sufficient size for (M, N, splits); hgemm_mi355x_release_workspaces
- * frees the library-owned buffers (call with no GEMM in flight). */
+ * frees the library-owned buffers (call with no GEMM in flight and no hipGraph that holds one still alive).
+ *
+ * hipGraph capture (launch-bound shapes: a 64x4096x64 call is ~3 us of kernel behind ~7 us of launch): every
+ * entry point may be called on a capturing stream -- the call records kernel nodes only, nothing is allocated,
+ * synchronised or memset during capture.  A split-K (or hybrid-tail) plan needs its workspace to exist before
+ * the capture starts: call hgemm_mi355x_reserve_workspace(M, N, K, stream) for the largest shape that will be
+ * captured on that stream (or run the shape once on it); otherwise the captured call runs with splits = 1.
+ * A buffer that a capture has used is never freed by later growth (it is retired until
+ * hgemm_mi355x_release_workspaces), so instantiated graphs stay valid.  Replays of graphs captured on one
+ * stream share that stream's workspace: do not replay them concurrently on several streams. */
 int hgemm_mi355x_set_workspace(void* device_ptr, size_t bytes);
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits);
+int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream);
 int hgemm_mi355x_release_workspaces(void);
 
 const char* hgemm_mi355x_strerror(int status);

@@ -379,6 +379,121 @@ def test_split_k_on_two_streams_does_not_share_partials(g, oracle):
             assert np.array_equal(c.cpu().numpy().view(np.uint16), p[3].view(np.uint16)), form
 
 
+def _graph_lib(g):
+    import ctypes
+
+    L = g.lib()
+    L.hgemm_mi355x_reserve_workspace.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    return L
+
+
+def _device_problem(oracle, m, n, k, seed):
+    a_np, b_np = oracle.zero_one_inputs(m, n, k, np.random.default_rng(seed))
+    return a_np, b_np
+
+
+def _truth_fast(a_np, b_np):
+    """The reference's CPU expression (zero_one_correctness_check.py:85-90) through torch's fp32 matmul: exact for
+    0/1 inputs whatever the summation order (every partial sum is an integer < 2^24), and quick at the large
+    shapes where the C restatement's scalar loop takes minutes (tests/test_oracle.py pins the two together)."""
+    return (torch.from_numpy(a_np).float() @ torch.from_numpy(b_np).float()).half().numpy()
+
+
+def test_hipgraph_capture_and_replay_is_exact(g, oracle):
+    """Every plan form records into a hipGraph (kernel nodes only) and the replay computes: library plans of a
+    launch-bound shape and of a hybrid-tail shape, explicit two-pass and single-launch split-K plans.  The graph
+    is replayed on NEW operand values written into the captured buffers (a cached result would be caught)."""
+    L = _graph_lib(g)
+    names = g.config_names()
+    t64 = names.index("t64x64_w2x2_m16_s4")
+    cases = [((64, 4096, 64), None), ((192, 320, 8192), (t64, 16, 1)), ((192, 320, 8192), (t64, 16 | 0x10000, 1)),
+             ((4352, 4352, 4096), None), ((520, 264, 200), None)]
+    s = torch.cuda.Stream()
+    bufs = []
+    for (m, n, k), plan in cases:
+        assert L.hgemm_mi355x_reserve_workspace(m, n, k, s.cuda_stream) == 0
+        bufs.append((torch.empty((m, k), dtype=torch.half, device="cuda"), torch.empty((k, n), dtype=torch.half, device="cuda"),
+                     torch.empty((n, k), dtype=torch.half, device="cuda"), torch.empty((m, n), dtype=torch.half, device="cuda")))
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        st = torch.cuda.current_stream().cuda_stream
+        for ((m, n, k), plan), (a, b, bt, c) in zip(cases, bufs):
+            if plan is None:
+                rc = L.hgemm_mi355x_fp32(a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, st)
+            else:
+                rc = L.hgemm_mi355x_launch(plan[0], plan[1], plan[2], a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(),
+                                           m, n, k, k, k, n, st)
+            assert rc == 0, L.hgemm_mi355x_strerror(rc)
+    for seed in (1, 2):
+        truths = []
+        for i, (((m, n, k), _), (a, b, bt, c)) in enumerate(zip(cases, bufs)):
+            a_np, b_np = _device_problem(oracle, m, n, k, 100 * seed + i)
+            a.copy_(torch.from_numpy(a_np)); b.copy_(torch.from_numpy(b_np)); bt.copy_(torch.from_numpy(np.ascontiguousarray(b_np.T)))
+            c.fill_(float("nan"))
+            truths.append(_truth_fast(a_np, b_np))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        for (shape, plan), (_, _, _, c), truth in zip(cases, bufs, truths):
+            assert np.array_equal(c.cpu().numpy().view(np.uint16), truth.view(np.uint16)), (shape, plan, seed)
+
+
+def test_hipgraph_capture_never_allocates_and_growth_keeps_graphs_valid(g, oracle):
+    """(i) A split-K plan captured on a stream that has no workspace yet runs without split-K (nothing may be
+    allocated while capturing) and is still exact.  (ii) A workspace a graph has captured survives a later growth
+    of that stream's workspace: the old graph replays correctly afterwards."""
+    L = _graph_lib(g)
+    names = g.config_names()
+    t64 = names.index("t64x64_w2x2_m16_s4")
+    m, n, k = 192, 320, 8192
+    a_np, b_np = _device_problem(oracle, m, n, k, 9)
+    truth = _truth_fast(a_np, b_np)
+    a, b = torch.from_numpy(a_np).cuda(), torch.from_numpy(b_np).cuda()
+    bt = b.t().contiguous()
+
+    def capture(stream, splits):
+        c = torch.full((m, n), float("nan"), dtype=torch.half, device="cuda")
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            rc = L.hgemm_mi355x_launch(t64, splits, 1, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, k, k, n,
+                                       torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, L.hgemm_mi355x_strerror(rc)
+        return graph, c
+
+    def replay_exact(graph, c):
+        c.fill_(float("nan"))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        return np.array_equal(c.cpu().numpy().view(np.uint16), truth.view(np.uint16))
+
+    fresh = torch.cuda.Stream()                       # (i) no workspace on this stream
+    for splits in (16, 16 | 0x10000):
+        graph, c = capture(fresh, splits)
+        assert replay_exact(graph, c)
+    s = torch.cuda.Stream()                           # (ii)
+    assert L.hgemm_mi355x_reserve_workspace(m, n, k, s.cuda_stream) == 0
+    graphs = [capture(s, 16), capture(s, 16 | 0x10000)]
+    assert all(replay_exact(gr, c) for gr, c in graphs)
+    big_m = big_n = 2560                              # 8 slabs of 2560^2 fp32 = 200 MiB > the 64 MiB first allocation
+    ba_np, bb_np = _device_problem(oracle, big_m, big_n, 512, 10)
+    with torch.cuda.stream(s):
+        ba, bb = torch.from_numpy(ba_np).cuda(), torch.from_numpy(bb_np).cuda()
+        bbt = bb.t().contiguous()
+        bc = torch.full((big_m, big_n), float("nan"), dtype=torch.half, device="cuda")
+        assert L.hgemm_mi355x_launch(t64, 8, 1, ba.data_ptr(), bb.data_ptr(), bbt.data_ptr(), bc.data_ptr(), big_m, big_n, 512, 512, 512,
+                                     big_n, s.cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(bc.cpu().numpy().view(np.uint16), _truth_fast(ba_np, bb_np).view(np.uint16))
+    for _ in range(3):
+        assert all(replay_exact(gr, c) for gr, c in graphs)
+    del graphs, graph
+    torch.cuda.synchronize()
+    assert L.hgemm_mi355x_release_workspaces() == 0
+
+
 def test_lent_workspace_too_small_degrades_to_no_split(g, oracle):
     import ctypes
 
