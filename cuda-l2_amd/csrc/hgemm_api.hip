@@ -200,6 +200,7 @@ void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     if (e.bm > M * 2 && e.bm > 32) continue;
     if (e.bn > N * 2 && e.bn > 32) continue;
     if (!k_ok(e, K)) continue;
+    if ((e.name[0] == 's' || e.name[0] == 'q') && e.mi == 32) continue;   // experimental 32x32x16 members: explicit plans only
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && ksteps / s < 4) break;
       const double t = model_us(e, M, N, K, s);

@@ -23,9 +23,9 @@ namespace hgemm_mi355x {
 #define HGEMM_SQINST_2(...)
 #define HGEMM_SQINST_3(...)
 #undef HGEMM_SQINST_3
-#define HGEMM_SQINST_3(BM, BN, WM, WN, KT) \
-  template void launch_sq<CfgSQ<BM, BN, WM, WN, KT>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
-#define HGEMM_SQ(G, BM, BN, WM, WN, KT) HGEMM_SQINST_##G(BM, BN, WM, WN, KT)
+#define HGEMM_SQINST_3(BM, BN, WM, WN, KT, MI) \
+  template void launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI) HGEMM_SQINST_##G(BM, BN, WM, WN, KT, MI)
 #define HGEMM_RSINST_0(...)
 #define HGEMM_RSINST_1(...)
 #define HGEMM_RSINST_2(...)

@@ -37,6 +37,9 @@
 #ifndef HGEMM_SQ_SLACK
 #define HGEMM_SQ_SLACK 6      // MFMA slots between the last leading fragment read and the sync point
 #endif
+#ifndef HGEMM_SQ_SLACK32
+#define HGEMM_SQ_SLACK32 4    // the same for the 32x32x16 members (their slots are 32 cycles long)
+#endif
 #ifndef HGEMM_SQ_RS64
 #define HGEMM_SQ_RS64 2       // leading reads every N slots when an interval has >= 64 slots
 #endif
@@ -55,11 +58,18 @@ namespace hgemm_mi355x {
 // KT = 2: a stage holds K = 128 as two complete BK=64 images ([A rows][B rows] each, same swizzle), an interval
 // is one sub-tile (two K=32 slices): twice the MFMA slots between sync points, which is what lets a 128x128
 // tile (16 MFMA tiles per wave) amortise its two barriers per stage.
-template <int BM_, int BN_, int WM_, int WN_, int KT_ = 1>
-struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
-  using Base = Cfg<BM_, BN_, WM_, WN_, 16, 2>;
+//
+// MI = 32 ("_m32"): the same schedule on v_mfma_f32_32x32x16_f16.  An interval (K = 32) is then TWO k = 16 MFMA
+// slices of FM x FN = 4 x 4 tiles: half the MFMA issues (each twice as long), the same eight ds_read_b128 per
+// operand and interval, half the operand-register reads per flop.  The slot plan is the generic one with 32-cycle
+// slots (RS = 1, its own slack).  KT = 1 only.
+template <int BM_, int BN_, int WM_, int WN_, int KT_ = 1, int MI_ = 16>
+struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, MI_, 2> {
+  using Base = Cfg<BM_, BN_, WM_, WN_, MI_, 2>;
   static constexpr int KT  = KT_;
-  static constexpr int SL  = KT;                           // K=32 MFMA slices per interval
+  static constexpr int KS  = (MI_ == 16) ? 1 : 2;          // MFMA k-slices per K = 32
+  static constexpr int SL  = KT * KS;                      // MFMA k-slices per interval
+  static constexpr int ACC = (MI_ == 16) ? 4 : 16;         // accumulator registers per MFMA tile
   static constexpr int SUB_BYTES   = Base::STAGE_BYTES;    // one BK=64 image: (BM + BN) rows x 128 B
   static constexpr int STAGE_BYTES = KT * SUB_BYTES;
   static constexpr int LDS_BYTES   = 2 * STAGE_BYTES;
@@ -69,16 +79,17 @@ struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, 16, 2> {
   static constexpr int PB  = Base::NJ - PA;
   static constexpr int NJA = KT * PA, NJB = KT * PB;       // ... per stage
   static constexpr int RS  = (T >= 64) ? HGEMM_SQ_RS64 : 1; // one leading fragment read every RS slots
-  static constexpr int SLACK = (T >= 64) ? HGEMM_SQ_SLACK : (T >= 32 ? 6 : 2);
+  static constexpr int SLACK = (MI_ == 32) ? HGEMM_SQ_SLACK32 : (T >= 64) ? HGEMM_SQ_SLACK : (T >= 32 ? 6 : 2);
   static constexpr int P   = RS * NFB + SLACK;             // slot of interval A that carries sync P
   static constexpr int Q   = RS * NFA + SLACK;             // slot of interval B that carries sync Q
   // behind a sync point a DMA piece and a fragment read alternate, one item every ST slots
   static constexpr int STA = (T - P - 1) / (NJB + NFA) >= 2 ? 2 : 1;
   static constexpr int STB = (T - Q - 1) / (NJA + NFB) >= 2 ? 2 : 1;
   static_assert(KT == 1 || KT == 2, "one or two BK=64 sub-tiles per stage");
+  static_assert(MI_ == 16 || (MI_ == 32 && KT == 1), "the 32x32x16 members hold K = 64 per stage");
   static_assert(Base::NI % Base::NW == 0 && Base::NI_A % Base::NW == 0, "every wave owns whole A and B pieces");
   static_assert(P + 1 + STA * (NJB + NFA) <= T && Q + 1 + STB * (NJA + NFB) <= T, "slot plan does not fit the interval");
-  static_assert(Base::FM * Base::FN * 4 <= 256, "accumulators live in a0..a255");
+  static_assert(Base::FM * Base::FN * ACC <= 256, "accumulators live in a0..a255");
   static_assert(LDS_BYTES + 64 <= 160 * 1024, "LDS budget");
 };
 
@@ -142,7 +153,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
   constexpr int NLEAD = PHASE == 0 ? CFG::NFB : CFG::NFA, FLEAD = PHASE == 0 ? FN : FM, FTRAIL = PHASE == 0 ? FM : FN;
 #pragma unroll
   for (int n = 0; n < T; ++n) {
-    const int u = n / (FM * FN), i = (n / FN) % FM, j = n % FN;   // K=32 slice, accumulator tile (i, j)
+    const int u = n / (FM * FN), i = (n / FN) % FM, j = n % FN;   // MFMA k-slice, accumulator tile (i, j)
     if (n == (PHASE == 0 ? CFG::P : CFG::Q)) {
       // every fragment read of the region about to be refilled has RETURNED (LDS returns in order, and the
       // leading reads were the last ones issued), and my pieces of the half-tile the trailing reads are
@@ -151,18 +162,18 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       wait_vmcnt<CFG::NJA + CFG::NJB>();
       sp_sync();
     }
-    sp_mfma(i * FN + j, bf[u * FN + j], af[u * FM + i]);
+    sp_mfma_mi<CFG::MI>(i * FN + j, bf[u * FN + j], af[u * FM + i]);
     if (n % RS == 0 && n / RS < NLEAD) {
       const int r = n / RS;
-      lead[r] = *(const f16x8*)((r / FLEAD ? lead1 : lead0) + (r % FLEAD) * 16 * ROW_BYTES);
+      lead[r] = *(const f16x8*)((r / FLEAD ? lead1 : lead0) + (r % FLEAD) * CFG::MI * ROW_BYTES);
     }
     if (PHASE == 0) {
       const int r = PL::a_read_at(n), p = PL::a_piece_at(n);
       if (p >= 0) sq_issue_piece<CFG, 1>(rs, voff, dma_stage, wave, p, kbyte);
-      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * 16 * ROW_BYTES);
+      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
     } else {
       const int r = PL::b_read_at(n), p = PL::b_piece_at(n);
-      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * 16 * ROW_BYTES);
+      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
       if (p >= 0) sq_issue_piece<CFG, 0>(rs, voff, dma_stage, wave, p, kbyte);
     }
   }
@@ -227,9 +238,10 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
   } while (0)
 
 // One pipeline step (K = 64 * KT) on stage (step & 1).  YS = second-half A fragments of the current tile,
-// ZS = where the next tile's go.  Fragment source of interval h, slice u: KT = 1: the stage image, chunk group h;
-// KT = 2: sub-tile image h, chunk group u.
-#define SQ_FRAG(STAGE, OPOFF, H, U) ((STAGE) + (CFG::KT == 2 ? (H) * CFG::SUB_BYTES : 0) + (OPOFF) + ((CFG::KT == 2 ? (U) : (H)) ? off1 : off0))
+// ZS = where the next tile's go.  Fragment source of interval h, slice u: KT = 1: the stage image, K = 32 half h
+// (MI = 32: its k = 16 slice u); KT = 2: sub-tile image h, K = 32 half u.
+#define SQ_FRAG(STAGE, OPOFF, H, U) ((STAGE) + (CFG::KT == 2 ? (H) * CFG::SUB_BYTES : 0) + (OPOFF) + \
+                                     foff[CFG::KT == 2 ? (U) : (H)][CFG::KT == 2 ? 0 : (U) % CFG::KS])
 #define SQ_K_STEP(YS, ZS)                                                                                       \
   do {                                                                                                          \
     char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                           \
@@ -245,8 +257,9 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ;
+  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ, MI = CFG::MI;
   constexpr int NFA = CFG::NFA, NFB = CFG::NFB;
+  constexpr int NQ = CFG::ACC / 4;              // f32x4 quads per accumulator tile
 
   // the two stages + one word for the single-launch split-K vote (ONE LDS object, see hgemm_kernel_sp.hpp)
   __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
@@ -260,9 +273,14 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   const ItemWalk walk = persistent_walk(g.items);
   if (walk.count == 0) return;
 
-  const int l15 = lane & 15, lq = lane >> 4, sw = l15 >> 1;
-  const int off0 = l15 * ROW_BYTES + (((0 * 4 + lq) ^ sw) << 4);
-  const int off1 = l15 * ROW_BYTES + (((1 * 4 + lq) ^ sw) << 4);
+  // fragment lane mapping (hgemm_kernel_sp.hpp): MI = 16: row lane & 15, 16-B chunk 4h + (lane >> 4);
+  // MI = 32: row lane & 31, chunk 4h + 2u + (lane >> 5); the image's swizzle is keyed on (row >> 1) & 7
+  const int lr = lane & (MI - 1), lq = lane / MI, sw = (lr >> 1) & 7;
+  int foff[2][CFG::KS];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int u = 0; u < CFG::KS; ++u) foff[h][u] = lr * ROW_BYTES + (((h * 4 + u * 2 + lq) ^ sw) << 4);
   const int a_base_off = wave_m * CFG::TM * ROW_BYTES;
   const int b_base_off = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
 
@@ -287,7 +305,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int n = 0; n < FM * FN; ++n) sp_zero_acc(n);
+  for (int n = 0; n < FM * FN * NQ; ++n) sp_zero_acc(n);
   wait_vmcnt<CFG::NJA + CFG::NJB>();   // tile 0 landed (tile 1 may fly)
   __builtin_amdgcn_s_barrier();
 
@@ -295,11 +313,11 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   f16x8 fX[NFA], fY[NFA], fZ[NFA], fU[NFB], fV[NFB];
 #pragma unroll
   for (int r = 0; r < NFA; ++r) {
-    fX[r] = *(const f16x8*)(SQ_FRAG(smem, a_base_off, 0, r / FM) + (r % FM) * 16 * ROW_BYTES);
-    fY[r] = *(const f16x8*)(SQ_FRAG(smem, a_base_off, 1, r / FM) + (r % FM) * 16 * ROW_BYTES);
+    fX[r] = *(const f16x8*)(SQ_FRAG(smem, a_base_off, 0, r / FM) + (r % FM) * MI * ROW_BYTES);
+    fY[r] = *(const f16x8*)(SQ_FRAG(smem, a_base_off, 1, r / FM) + (r % FM) * MI * ROW_BYTES);
   }
 #pragma unroll
-  for (int r = 0; r < NFB; ++r) fU[r] = *(const f16x8*)(SQ_FRAG(smem, b_base_off, 0, r / FN) + (r % FN) * 16 * ROW_BYTES);
+  for (int r = 0; r < NFB; ++r) fU[r] = *(const f16x8*)(SQ_FRAG(smem, b_base_off, 0, r / FN) + (r % FN) * MI * ROW_BYTES);
   // the A region of stage 0 is consumed: A(2) goes there (sync = the "Q" of a virtual K-step -1)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   sp_sync();
@@ -337,44 +355,89 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma unroll
       for (int r = 0; r < NFA; ++r) fY[r] = fZ[r];
     }
-    // ---- epilogue of this work item (as family "s"): row by row, one fragment row live in VGPRs ----------
+    // ---- epilogue of this work item (as family "s"): unit by unit (MI = 16: one fragment row, MI = 32: one tile) ---
     sp_mfma_drain();
     const bool rezero = item + 1 < walk.count;
     const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
-    (void)rsP;
+    const int m_wave = tc.m0 + wave_m * CFG::TM, n_wave = tc.n0 + wave_n * CFG::TN;
+    (void)rsP; (void)m_wave; (void)n_wave;
+    if constexpr (MI == 16) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 row[FN];
+      for (int i = 0; i < FM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 row[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
-      if (rezero) {
+        for (int j = 0; j < FN; ++j) row[j] = sp_read_acc(i * FN + j);
+        if (rezero) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+          for (int j = 0; j < FN; ++j) sp_zero_acc(i * FN + j);
+        }
+        if constexpr (EPI == SP_EPI_FUSED) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, BM * BN, i * FN + j, tid), row[j]);
+        } else {
+          if (!HGEMM_DBG(g, 2))
+            store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+        }
       }
-      if constexpr (EPI == SP_EPI_FUSED) {
+    } else {   // one 32x32 tile (16 registers) live at a time, as family "s"
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, BM * BN, i * FN + j, tid), row[j]);
-      } else {
-        if (!HGEMM_DBG(g, 2))
-          store_tile_row<16, FN, CFG::TM, CFG::TN, EPI == SP_EPI_SLAB, EPI == SP_EPI_SLAB ? -1 : EPI>(g, tc, wave_m, wave_n, lane, i, row);
+      for (int x = 0; x < FM * FN; ++x) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int i = x / FN, j = x % FN;
+        f32x4 qd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qd[q] = sp_read_acc(x * 4 + q);
+        if (rezero) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sp_zero_acc(x * 4 + q);
+        }
+        if constexpr (EPI == SP_EPI_FUSED) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, BM * BN, x * 4 + q, tid), qd[q]);
+        } else if constexpr (EPI == SP_EPI_SLAB) {
+          const int m = m_wave + i * 32 + (lane & 31);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n_wave + j * 32 + 8 * q + 4 * (lane >> 5);
+            if (m < g.M && n < g.N) *(f32x4*)(tc.slab + (size_t)(m - tc.m0) * tc.slab_ld + (n - tc.n0)) = qd[q];
+          }
+        } else {
+          if (!HGEMM_DBG(g, 2)) sp_store_tile32<EPI>(g, m_wave + i * 32 + (lane & 31), n_wave + j * 32, lane, qd);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (EPI == SP_EPI_FUSED) {
       if (fused_publish_and_vote(g, tc.tile, (volatile unsigned*)(smem + CFG::LDS_BYTES), tid)) {
         const int tiles = g.tiles_m * g.tiles_n;
+        if constexpr (MI == 16) {
 #pragma unroll 1
-        for (int i = 0; i < FM; ++i) {
-          f32x4 row[FN];
-          for (int sidx = 0; sidx < g.splits; ++sidx) {
+          for (int i = 0; i < FM; ++i) {
+            f32x4 row[FN];
+            for (int sidx = 0; sidx < g.splits; ++sidx) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-              const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
-              row[j] = (sidx == 0) ? v : row[j] + v;
+              for (int j = 0; j < FN; ++j) {
+                const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
+                row[j] = (sidx == 0) ? v : row[j] + v;
+              }
             }
+            store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
           }
-          store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
+        } else {
+#pragma unroll 1
+          for (int x = 0; x < FM * FN; ++x) {
+            const int i = x / FN, j = x % FN;
+            f32x4 qd[4];
+            for (int sidx = 0; sidx < g.splits; ++sidx) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, x * 4 + q, tid));
+                qd[q] = (sidx == 0) ? v : qd[q] + v;
+              }
+            }
+            sp_store_tile32<-1>(g, m_wave + i * 32 + (lane & 31), n_wave + j * 32, lane, qd);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);

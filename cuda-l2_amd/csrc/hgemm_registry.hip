@@ -10,8 +10,8 @@ namespace hgemm_mi355x {
   extern template void launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_SP(G, BM, BN, WM, WN, MI) \
   extern template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
-#define HGEMM_SQ(G, BM, BN, WM, WN, KT) \
-  extern template void launch_sq<CfgSQ<BM, BN, WM, WN, KT>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI) \
+  extern template void launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_RS(G, BM, BN, BKS) \
   extern template void launch_rs<CfgRS<BM, BN, BKS>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #include "hgemm_configs.def"
@@ -31,7 +31,7 @@ thread_local LaunchTiming t_launch_timing;
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
    Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true, 64, true},
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
-#define HGEMM_SQ(G, BM, BN, WM, WN, KT)
+#define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)
 #define HGEMM_RS(G, BM, BN, BKS)
 const KernelEntry g_kernel_table[] = {
 #include "hgemm_configs.def"
@@ -48,12 +48,13 @@ const KernelEntry g_kernel_table[] = {
   {HGEMM_SP_NAME_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2,                                      \
    CfgSP<BM, BN, WM, WN, MI>::THREADS, CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64,                  \
    &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64)), true, 64, false},
-#define HGEMM_SQ_NAME_1(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
-#define HGEMM_SQ_NAME_2(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_k128"
-#define HGEMM_SQ(G, BM, BN, WM, WN, KT)                                                                     \
-  {HGEMM_SQ_NAME_##KT(BM, BN, WM, WN), BM, BN, WM, WN, 16, 2, CfgSQ<BM, BN, WM, WN, KT>::THREADS,              \
-   CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT>>,                          \
-   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT>::LDS_BYTES + 64)), true, 64 * KT, false},
+#define HGEMM_SQ_NAME_1_16(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
+#define HGEMM_SQ_NAME_2_16(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_k128"
+#define HGEMM_SQ_NAME_1_32(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m32"
+#define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)                                                                     \
+  {HGEMM_SQ_NAME_##KT##_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2, CfgSQ<BM, BN, WM, WN, KT, MI>::THREADS,      \
+   CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>,                      \
+   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64)), true, 64 * KT, false},
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
@@ -61,7 +62,7 @@ const KernelEntry g_kernel_table[] = {
 #undef HGEMM_RS
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
-#define HGEMM_SQ(G, BM, BN, WM, WN, KT)
+#define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)
 #define HGEMM_RS(G, BM, BN, BKS)                                                                            \
   {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS), BM, BN, 2, 2, 16, 1, CfgRS<BM, BN, BKS>::THREADS,  \
    CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS, false},

@@ -1,6 +1,6 @@
 // hgemm_tune -- native (no torch) checker / autotuner / micro-benchmark for libhgemm_mi355x.so.
 //
-//   hgemm_tune check [--shapes M_N_K,...]            every geometry x split-K form, BIT-EXACT against an exact
+//   hgemm_tune check [--shapes M_N_K,...] [--configs a,b]   every (or the named) geometry x split-K form, BIT-EXACT against an exact
 //                                                     integer reference on the reference's {0,1} inputs
 //                                                     (zero_one_correctness_check.py:65-92,263-268)
 //   hgemm_tune tune  --shapes M_N_K,... | --shape-file F  [--out F.jsonl] [--keep R] [--baselines]
@@ -248,6 +248,8 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     for (int c = HGEMM_CONFIG_RAGGED; c < nc; ++c) {
       if (c >= 0 && sh.K % 64 == 0 && sh.K % hgemm_mi355x_config_k_granularity(c) != 0) continue;  // BK=128 member, K = 64 (mod 128)
       const char* cname = c >= 0 ? hgemm_mi355x_config_name(c) : (c == HGEMM_CONFIG_GENERIC ? "generic" : "ragged");
+      if (!g_config_filter.empty() && std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) == g_config_filter.end())
+        continue;   // --configs: only these (the special ids are "generic" / "ragged")
       for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED}) {
         const int sp = splits & HGEMM_SPLITK_MASK;
         if (sp > 1 && (c < 0 || sh.K / 64 < sp)) continue;

@@ -251,13 +251,15 @@ def sp_plan(FM: int, FN: int, NJA: int, NJB: int, RS: int = 2):
 
 
 # ---- family "q" (hgemm_kernel_sq.hpp): early-A operand split, two sync points per pipeline stage ---------------
-def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, rs64: int = 2):
+def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, rs64: int = 2, MI: int = 16, slack32: int = 4):
     """Mirror of CfgSQ / SqPlan: slot numbers of the leading reads, the sync point and the (DMA piece, trailing read)
-    items of interval A (phase 0) and interval B (phase 1)."""
-    NFA, NFB, T = FM * KT, FN * KT, FM * FN * KT
+    items of interval A (phase 0) and interval B (phase 1).  FM, FN = MFMA tiles per wave tile (TM / MI, TN / MI);
+    MI = 32 runs two k = 16 MFMA slices per K = 32 interval."""
+    SL = KT * (1 if MI == 16 else 2)
+    NFA, NFB, T = FM * SL, FN * SL, FM * FN * SL
     NJA, NJB = KT * PA, KT * PB
     RS = rs64 if T >= 64 else 1
-    slack = slack64 if T >= 64 else (6 if T >= 32 else 2)
+    slack = slack32 if MI == 32 else slack64 if T >= 64 else (6 if T >= 32 else 2)
     P, Q = RS * NFB + slack, RS * NFA + slack
     STA = 2 if (T - P - 1) // (NJB + NFA) >= 2 else 1
     STB = 2 if (T - Q - 1) // (NJA + NFB) >= 2 else 1

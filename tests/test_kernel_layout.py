@@ -158,15 +158,25 @@ def test_sp_slot_plan_counts_match_the_waits(bm, bn):
     assert NJA + NJB <= 63 and NJA + p["NB1"] <= 63          # vmcnt is a 6-bit counter
 
 
-@pytest.mark.parametrize("bm,bn,kt", [(256, 256, 1), (256, 128, 1), (128, 256, 1), (128, 128, 2), (128, 128, 1)])
-def test_family_q_schedule_has_no_lds_hazard(bm, bn, kt):
+def _sq_members(pkg_dir=None):
+    from pathlib import Path
+
+    text = (Path(__file__).resolve().parent.parent / "cuda-l2_amd" / "csrc" / "hgemm_configs.def").read_text()
+    out = [tuple(map(int, m.groups()[1:])) for m in
+           re.finditer(r"^HGEMM_SQ\(\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", text, re.M)]
+    assert len(out) >= 6
+    return out
+
+
+@pytest.mark.parametrize("bm,bn,wm,wn,kt,mi", _sq_members())
+def test_family_q_schedule_has_no_lds_hazard(bm, bn, wm, wn, kt, mi):
     """Family q (hgemm_kernel_sq.hpp) orders its LDS traffic with TWO sync points per stage; the counted vmcnt and the
     slot positions are replayed here for every instantiated geometry (the knob values of the experiment builds too)."""
-    nw, wm, wn = 4, 2, 2
-    FM, FN = bm // wm // 16, bn // wn // 16
+    nw = wm * wn
+    FM, FN = bm // wm // mi, bn // wn // mi
     PA, PB = bm // 8 // nw, bn // 8 // nw
     for slack, rs in [(6, 2), (2, 2), (12, 2), (6, 1)]:
-        plan = klm.sq_plan(FM, FN, PA, PB, kt, slack, rs)
+        plan = klm.sq_plan(FM, FN, PA, PB, kt, slack, rs, mi, slack32=min(slack, 6))
         T = plan["T"]
         slots = plan["pieces_A"] + plan["reads_A"]
         assert len(set(slots)) == len(slots) and max(slots) < T and min(slots) > plan["P"]
