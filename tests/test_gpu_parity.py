@@ -577,6 +577,10 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("q256x256_w2x2", 1, (1024, 1536, 2048)),          # early-A split, persistent (24 tiles)
         ("q256x256_w2x2", 1, (4608, 4608, 576)),           # ... several items per workgroup, odd K-step count (9)
         ("q256x128_w2x2", 1, (4352, 4352, 1024)),          # ... hybrid tail
+        ("q256x256_w2x2_m32", 1, (1024, 1536, 2048)),      # early-A split on the 32x32x16 MFMA
+        ("q256x256_w2x2_m32", 1, (4608, 4608, 576)),       # ... several items per workgroup, odd K-step count
+        ("q256x256_w2x2_m32", 4 | 0x10000, (1024, 1024, 4096)),  # ... single-launch split-K
+        ("q256x256_w2x2_m32", 3, (1100, 1000, 4096)),      # ... two-pass split-K, ragged edges
         ("q128x256_w2x2", 3, (1024, 1024, 4096)),          # ... two-pass split-K
         ("s256x256_w2x2", 4 | 0x10000, (1024, 1024, 4096)),# SP + single-launch split-K
         ("s128x256_w2x2", 3, (1024, 1024, 4096)),          # SP + two-pass split-K
