@@ -123,7 +123,7 @@ def build_tools(verbose: bool = False) -> list[Path]:
         want = obj.name + lib.name + str(lib.stat().st_mtime_ns)
         if not (exe.exists() and stamp.exists() and stamp.read_text() == want):
             _run([HIPCC, f"--offload-arch={ARCH}", str(obj), "-o", str(exe), f"-L{LIB_DIR}", "-lhgemm_mi355x",
-                  f"-L{ROCM / 'lib'}", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}"],
+                  f"-L{ROCM / 'lib'}", "-lamdhip64", "-lrocm_smi64", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM / 'lib'}"],
                  verbose)
             stamp.write_text(want)
         out.append(exe)

@@ -7,6 +7,10 @@
 //                                                     time candidate plans, print one JSON line per shape
 //   hgemm_tune bench --shape M_N_K [--config NAME --splits S --group G] [--reps N] [--lib]
 //                                                     run one plan N times (for rocprofv3)
+//   hgemm_tune bench --shape M_N_K --power [--seconds S] [--baseline hipblaslt_tn|hipblaslt_nn|rocblas_tn] [...]
+//                                                     back-to-back launches for S seconds (no sync in between); reports
+//                                                     us per call and the board's gfx clock / socket power sampled over
+//                                                     the timed region (rocm_smi gpu metrics, every 10 ms)
 //
 // This is the offline replacement for the reference's first-call in-process autotune variants
 // (h100 kernels that time several variants on first invocation): plans are
@@ -23,8 +27,13 @@
 #include <cstdint>
 #include <fstream>
 #include <sstream>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <rocm_smi/rocm_smi.h>
 
 #include "../../../include/hgemm_mi355x.h"
 
@@ -420,6 +429,103 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Board telemetry over a timed region: the compute-bound shapes run power-limited, so what a
+// kernel sustains is (cycles per flop) x (clock the board grants it at the power cap).  Sampled from the SMU's
+// gpu-metrics table through rocm_smi; the HIP device is matched to its rocm_smi index by PCI address.
+struct BoardSampler {
+  bool ok = false;
+  uint32_t dv = 0;
+  std::thread th;
+  std::atomic<bool> stop{false};
+  double sum_mhz = 0, sum_w = 0, max_w = 0, min_mhz = 1e9;
+  int n = 0;
+  bool open() {
+    if (rsmi_init(0) != RSMI_STATUS_SUCCESS) return false;
+    uint32_t num = 0;
+    if (rsmi_num_monitor_devices(&num) != RSMI_STATUS_SUCCESS || num == 0) return false;
+    int dev = 0, dom = 0, bus = 0, slot = 0;
+    HIP_OK(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev);
+    (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev);
+    (void)hipDeviceGetAttribute(&slot, hipDeviceAttributePciDeviceId, dev);
+    dv = 0;
+    for (uint32_t i = 0; i < num; ++i) {
+      uint64_t bdf = 0;
+      if (rsmi_dev_pci_id_get(i, &bdf) != RSMI_STATUS_SUCCESS) continue;
+      if ((int)((bdf >> 8) & 0xff) == bus && (int)((bdf >> 3) & 0x1f) == slot && (int)((bdf >> 32) & 0xffffffff) == dom) { dv = i; break; }
+    }
+    ok = true;
+    return true;
+  }
+  void sample() {
+    rsmi_gpu_metrics_t m;
+    memset(&m, 0, sizeof m);
+    if (rsmi_dev_gpu_metrics_info_get(dv, &m) != RSMI_STATUS_SUCCESS) return;
+    double mhz = 0; int k = 0;
+    for (int x = 0; x < RSMI_MAX_NUM_GFX_CLKS; ++x)
+      if (m.current_gfxclks[x] != 0 && m.current_gfxclks[x] != 0xFFFF) { mhz += m.current_gfxclks[x]; ++k; }
+    if (k) mhz /= k; else if (m.current_gfxclk != 0xFFFF) mhz = m.current_gfxclk;
+    double w = (m.current_socket_power != 0xFFFF) ? m.current_socket_power : (m.average_socket_power != 0xFFFF ? m.average_socket_power : 0);
+    if (mhz > 0) { sum_mhz += mhz; min_mhz = std::min(min_mhz, mhz); }
+    sum_w += w; max_w = std::max(max_w, w);
+    ++n;
+  }
+  void start() {
+    if (!ok) return;
+    stop = false;
+    th = std::thread([this] { while (!stop.load()) { sample(); std::this_thread::sleep_for(std::chrono::milliseconds(10)); } });
+  }
+  void finish() {
+    if (!ok) return;
+    stop = true;
+    if (th.joinable()) th.join();
+  }
+};
+
+// back-to-back launches for `seconds` (one event pair around the whole run): us per call in steady state + telemetry
+template <class F>
+static int power_bench(const Shape& sh, const char* label, F&& launch, std::vector<Buffers>& sets, double seconds) {
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  // calibrate: 20 launches, then size the warm-up (0.5 s) and the timed run
+  for (int i = 0; i < 20; ++i)
+    if (launch(sets[i % sets.size()]) != HGEMM_OK) { fprintf(stderr, "power: launch failed\n"); return 1; }
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < 20; ++i) (void)launch(sets[i % sets.size()]);
+  HIP_OK(hipEventRecord(e1, nullptr));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  const double est_us = std::max(1.0, ms * 1000.0 / 20);
+  const int warm = (int)std::min(200000.0, 0.5e6 / est_us) + 1, reps = (int)std::min(2000000.0, seconds * 1e6 / est_us) + 1;
+  for (int i = 0; i < warm; ++i) (void)launch(sets[i % sets.size()]);
+  BoardSampler bs;
+  bs.open();
+  HIP_OK(hipEventRecord(e0, nullptr));
+  bs.start();
+  for (int i = 0; i < reps; ++i) {
+    if (launch(sets[i % sets.size()]) != HGEMM_OK) { bs.finish(); fprintf(stderr, "power: launch failed\n"); return 1; }
+  }
+  HIP_OK(hipEventRecord(e1, nullptr));
+  HIP_OK(hipEventSynchronize(e1));
+  bs.finish();
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1000.0 / reps, flops = 2.0 * sh.M * sh.N * (double)sh.K;
+  printf("{\"mnk\": \"%d_%d_%d\", \"what\": \"%s\", \"mode\": \"stream\", \"us\": %.3f, \"tflops\": %.2f, \"reps\": %d, \"seconds\": %.3f, "
+         "\"telemetry\": {\"samples\": %d, \"gfx_mhz_mean\": %.1f, \"gfx_mhz_min\": %.1f, \"socket_w_mean\": %.1f, \"socket_w_max\": %.1f}}\n",
+         sh.M, sh.N, sh.K, label, us, flops / us * 1e-6, reps, ms * 1e-3, bs.n, bs.n ? bs.sum_mhz / bs.n : 0.0, bs.n ? bs.min_mhz : 0.0,
+         bs.n ? bs.sum_w / bs.n : 0.0, bs.max_w);
+  fflush(stdout);
+  return 0;
+}
+
+static const char* g_baseline = nullptr;   // bench --baseline
+static bool g_power = false;               // bench --power
+static double g_seconds = 1.5;             // bench --seconds
+
 static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int group, int reps, bool use_lib_plan) {
   int cfg = -2;
   if (use_lib_plan || !cfg_name) {
@@ -432,7 +538,7 @@ static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int grou
   const size_t set_bytes = 2 * ((size_t)sh.M * sh.K + (size_t)sh.N * sh.K + (size_t)sh.M * sh.N);
   int nsets = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)320 << 20) / set_bytes + 1));
   std::vector<Buffers> sets(nsets);
-  for (int i = 0; i < nsets; ++i) alloc_set(sets[i], sh, 5 + i, false);
+  for (int i = 0; i < nsets; ++i) alloc_set(sets[i], sh, 5 + i, g_baseline != nullptr);
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
@@ -440,6 +546,30 @@ static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int grou
   auto launch = [&](Buffers& s) {
     return hgemm_mi355x_launch(cfg, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, ld, ld, sh.N, nullptr);
   };
+  if (g_baseline) {
+    const std::string b = g_baseline;
+    int rc = 0;
+    if (b == "rocblas_tn") {
+      hgemm_rocblas_init();
+      rc = power_bench(sh, g_baseline, [&](Buffers& s) { return hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, g_seconds);
+    } else if (b == "hipblaslt_tn" || b == "hipblaslt_nn") {
+      hgemm_hipblaslt_heuristic_init();
+      const bool tn = b == "hipblaslt_tn";
+      rc = power_bench(sh, g_baseline, [&](Buffers& s) {
+        return tn ? hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr)
+                  : hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, g_seconds);
+    } else {
+      fprintf(stderr, "unknown --baseline %s\n", g_baseline);
+      rc = 2;
+    }
+    for (auto& s : sets) free_set(s);
+    return rc;
+  }
+  if (g_power) {
+    const int rc = power_bench(sh, cfg >= 0 ? hgemm_mi355x_config_name(cfg) : "generic", launch, sets, g_seconds);
+    for (auto& s : sets) free_set(s);
+    return rc;
+  }
   const double us = time_us(launch, sets, 3, reps, e0, e1);
   if (us >= kFailedUs) { fprintf(stderr, "bench: launch failed\n"); return 1; }
   const double flops = 2.0 * sh.M * sh.N * (double)sh.K;
@@ -480,6 +610,9 @@ int main(int argc, char** argv) {
     else if (a == "--group") group = atoi(next());
     else if (a == "--reps") reps = atoi(next());
     else if (a == "--lib") use_lib = true;
+    else if (a == "--power") g_power = true;
+    else if (a == "--seconds") g_seconds = atof(next());
+    else if (a == "--baseline") { g_baseline = next(); g_power = true; }
     else if (a == "--ld") g_ld_override = atoi(next());
     else if (a == "--debug") {
       if (!hgemm_mi355x_set_debug) { fprintf(stderr, "--debug needs the ablation build of the library (lib_ablation/)\n"); return 2; }
