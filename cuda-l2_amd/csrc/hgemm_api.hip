@@ -444,6 +444,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
           // (no workspace just means: no hybrid schedule)
           if (ensure_workspace((size_t)t.items * e.bm * e.bn * sizeof(float), s, &t.partial, &unused) == HGEMM_OK) {
             g.items = (int)full;
+            set_raster_div(g); set_raster_div(t);
             e.launch(g, (int)std::min<long>(full, G), s, EPI_C16, timing_slot(true, false));
             e.launch(t, (int)std::min<long>(t.items, G), s, EPI_SLAB, timing_slot(false, false));
             launch_tail_reduce(t, e.bm, e.bn, s, timing_slot(false, true));
@@ -456,6 +457,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     }
     // persistent families walk their work items themselves: one resident wave of workgroups
     const long launch_grid = (e.persistent_wgs > 0) ? std::min<long>(grid, e.persistent_wgs) : grid;
+    set_raster_div(g);
     e.launch(g, (int)launch_grid, s, epi, timing_slot(true, epi != EPI_SLAB));
     if (epi == EPI_SLAB) launch_splitk_reduce(g.partial, g.C, M, N, ldc, splits, s, timing_slot(false, true));
   }
@@ -473,6 +475,20 @@ int hgemm_mi355x_fp16(const void* a, const void* b, const void* bt, void* c, int
                       void* stream) {
   return run(HGEMM_ACC_FP16, a, b, bt, c, M, N, K, stream);
 }
+
+// Host-side self-check hook (tests/test_host_logic.py; not part of the public header): the raster map of the
+// kernels evaluated on the host, with true divisions (use_fast = 0) or with the multipliers the launch path would
+// pass (use_fast = 1).  out = {split, tile, tile_m, tile_n}.
+int hgemm_mi355x_selfcheck_raster(int tiles_m, int tiles_n, int group_m, int tail_first, int tail_tiles, int bid, int use_fast,
+                                  int out[4]) {
+  if (tiles_m < 1 || tiles_n < 1 || group_m < 1 || bid < 0 || !out) return HGEMM_ERR_BAD_ARG;
+  const RasterPos r = use_fast ? raster_fast(bid, tiles_m, tiles_n, group_m, tail_first, tail_tiles,
+                                             make_raster_div(tiles_m, tiles_n, group_m, tail_tiles))
+                               : raster_ref(bid, tiles_m, tiles_n, group_m, tail_first, tail_tiles);
+  out[0] = r.split; out[1] = r.tile; out[2] = r.tile_m; out[3] = r.tile_n;
+  return HGEMM_OK;
+}
+unsigned hgemm_mi355x_selfcheck_fastdiv(unsigned n, unsigned d) { return d ? fast_div(n, make_fast_div(d)) : 0xFFFFFFFFu; }
 
 const char* hgemm_mi355x_strerror(int status) {
   switch (status) {

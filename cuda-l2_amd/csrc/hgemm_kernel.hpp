@@ -63,6 +63,70 @@ constexpr int NUM_XCD   = 8;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// ---- exact unsigned division by a launch constant (Granlund-Montgomery, 32-bit): the raster map below divides a
+// work-item id by three launch constants; a hardware-less integer division is ~40 instructions with a v_rcp in its
+// dependency chain, five of them are most of a kernel's prologue and ~700 cycles per work item of a persistent
+// kernel.  With HGEMM_FASTDIV the host passes multipliers (GemmArgs::rd) and a division is s_mul_hi + 4 ALU ops.
+// tests/test_host_logic.py compares raster_fast with raster_ref on the host for every id of many launch shapes.
+#ifndef HGEMM_FASTDIV
+#define HGEMM_FASTDIV 0
+#endif
+struct FastDiv { uint32_t mul, sh1, sh2; };   // n / d = (t + ((n - t) >> sh1)) >> sh2,  t = mulhi(n, mul)
+__host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t t = __umulhi(n, f.mul);
+#else
+  const uint32_t t = (uint32_t)(((uint64_t)n * f.mul) >> 32);
+#endif
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+inline FastDiv make_fast_div(uint32_t d) {   // host side; d >= 1
+  FastDiv f{0u, 0u, 0u};                     // d == 1: t = 0, n >> 0 >> 0
+  if (d <= 1) return f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;               // l = ceil(log2 d), 1 <= l <= 32
+  f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+  f.sh1 = 1; f.sh2 = l - 1;
+  return f;
+}
+// divisors of the raster map: ids per split (tiles, or tail_tiles in the hybrid tail pass), ids per raster group
+// (group_m * tiles_n), group height (group_m) and the height of the last, partial group (tiles_m % group_m)
+struct RasterDiv { FastDiv per_split, per_group, gm_full, gm_last; };
+struct RasterPos { int split, tile, tile_m, tile_n; };   // K slice, output-tile id in raster order, tile coordinates
+
+// id -> (split, tile, tile row, tile column), grouped raster: groups of group_m tile rows, column-major inside a group
+__host__ __device__ __forceinline__ RasterPos raster_ref(int bid, int tiles_m, int tiles_n, int group_m, int tail_first, int tail_tiles) {
+  const int per = tail_tiles > 0 ? tail_tiles : tiles_m * tiles_n;
+  RasterPos r;
+  r.split = bid / per;
+  r.tile = (tail_tiles > 0 ? tail_first : 0) + (bid - r.split * per);
+  const int gsz = group_m * tiles_n, grp = r.tile / gsz, first_m = grp * group_m;
+  const int rest = tiles_m - first_m, gm = rest < group_m ? rest : group_m, tin = r.tile - grp * gsz;
+  r.tile_m = first_m + tin % gm;
+  r.tile_n = tin / gm;
+  return r;
+}
+__host__ __device__ __forceinline__ RasterPos raster_fast(int bid, int tiles_m, int tiles_n, int group_m, int tail_first, int tail_tiles,
+                                                          const RasterDiv& d) {
+  const int per = tail_tiles > 0 ? tail_tiles : tiles_m * tiles_n;
+  RasterPos r;
+  r.split = (int)fast_div((uint32_t)bid, d.per_split);
+  r.tile = (tail_tiles > 0 ? tail_first : 0) + (bid - r.split * per);
+  const int gsz = group_m * tiles_n, grp = (int)fast_div((uint32_t)r.tile, d.per_group), first_m = grp * group_m;
+  const int rest = tiles_m - first_m, gm = rest < group_m ? rest : group_m, tin = r.tile - grp * gsz;
+  r.tile_n = (int)fast_div((uint32_t)tin, gm == group_m ? d.gm_full : d.gm_last);
+  r.tile_m = first_m + (tin - r.tile_n * gm);
+  return r;
+}
+inline RasterDiv make_raster_div(int tiles_m, int tiles_n, int group_m, int tail_tiles) {   // host side
+  RasterDiv d;
+  d.per_split = make_fast_div((uint32_t)(tail_tiles > 0 ? tail_tiles : tiles_m * tiles_n));
+  d.per_group = make_fast_div((uint32_t)(group_m * tiles_n));
+  d.gm_full = make_fast_div((uint32_t)group_m);
+  d.gm_last = make_fast_div((uint32_t)(tiles_m % group_m ? tiles_m % group_m : 1));
+  return d;
+}
+
 struct GemmArgs {
   const f16* A;    // [M][lda]
   const f16* Bt;   // [N][ldb]   (b_col_major: B transposed, K contiguous)
@@ -83,11 +147,21 @@ struct GemmArgs {
   // Single-launch split-K (EPI_FUSED): one arrival counter per output tile (zero before the launch, reset
   // by the last arriver) and compact per-item slabs partial[item][BM*BN] in the kernel's own lane order.
   unsigned* counters;
+#if HGEMM_FASTDIV
+  RasterDiv rd;    // multipliers for the raster map's divisions (set_raster_div on the host, after the fields above are final)
+#endif
 #ifdef HGEMM_ABLATION
   int debug;       // tuner-only build (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
                    // epilogue stores, bit 2 cut every tile's K loop to two steps, bit 3 every tile stores to tile (0,0)
 #endif
 };
+inline void set_raster_div(GemmArgs& g) {   // host: after tiles_m / tiles_n / group_m / tail_tiles are final
+#if HGEMM_FASTDIV
+  g.rd = make_raster_div(g.tiles_m, g.tiles_n, g.group_m, g.tail_tiles);
+#else
+  (void)g;
+#endif
+}
 
 // Ablation switches exist only in the tuner's -DHGEMM_ABLATION build of the library (lib_ablation/);
 // in the shipping library they fold to `false` and the branches disappear.
@@ -144,6 +218,16 @@ struct TileCoord {
 
 // logical work-item id (after the XCD remap) -> (split, tile origin, K range), grouped raster
 __device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int BM, int BN) {
+#if HGEMM_FASTDIV
+  const RasterPos rp = raster_fast(bid, g.tiles_m, g.tiles_n, g.group_m, g.tail_first, g.tail_tiles, g.rd);
+  const int split = rp.split;
+  TileCoord tc;
+  tc.split = split;
+  tc.tile = rp.tile;
+  tc.item = bid;
+  tc.m0 = rp.tile_m * BM;
+  tc.n0 = rp.tile_n * BN;
+#else   // (the same map as raster_ref, kept in this form: the shipped binaries were validated with it)
   const int tiles = g.tiles_m * g.tiles_n;
   int split, t_id;
   if (g.tail_tiles > 0) {
@@ -164,6 +248,7 @@ __device__ __forceinline__ TileCoord map_logical(const GemmArgs& g, int bid, int
   tc.item = bid;
   tc.m0 = (first_m + tin % gm) * BM;
   tc.n0 = (tin / gm) * BN;
+#endif
   tc.k_begin = split * g.k_chunk;
   tc.nk = (min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin + BK - 1) / BK;   // the last K-step may be partial (classic family)
   if (HGEMM_DBG(g, 4)) tc.nk = min(tc.nk, 2);

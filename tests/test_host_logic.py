@@ -352,3 +352,52 @@ def test_report_tools_on_synthetic_inputs(tmp_path):
     assert abs(summ["derived"]["effective_clock_ghz"] - 2.0) < 1e-9            # 1.6e6 cycles / 8 XCDs / 100 us
     assert abs(summ["derived"]["mfma_pipe_busy_frac"] - 0.5) < 1e-9            # 1.024e8 / (1024 SIMDs * 2e5 cycles)
     assert summ["dominant_kernel"]["hbm_bytes_per_launch"] == (2 * 1000 + 500) * 1024
+
+
+def test_fast_division_is_exact(lib):
+    """hgemm_kernel.hpp fast_div / make_fast_div (the multipliers a launch passes to the kernels' raster map when
+    built with HGEMM_FASTDIV): exact for every 32-bit dividend, checked on edge values and a random sample."""
+    import random
+
+    f = lib.hgemm_mi355x_selfcheck_fastdiv
+    f.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    f.restype = ctypes.c_uint
+    rnd = random.Random(5)
+    divisors = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000, 1023, 1024, 1025,
+                4095, 4096, 4097, 65535, 65536, 65537, 262144, (1 << 24) - 1, 1 << 24, (1 << 31) - 1, 1 << 31, (1 << 32) - 1]
+    divisors += [rnd.randrange(1, 1 << rnd.randrange(1, 33)) for _ in range(200)]
+    for d in divisors:
+        ns = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, ((1 << 32) - 1) // d * d, ((1 << 32) - 1) // d * d - 1}
+        ns |= {rnd.randrange(0, 1 << 32) for _ in range(40)} | {rnd.randrange(0, 1 << 16) for _ in range(10)}
+        for n in ns:
+            if 0 <= n < (1 << 32):
+                assert f(n, d) == n // d, (n, d)
+
+
+def test_raster_map_fast_equals_reference_and_is_a_bijection(lib):
+    """The kernels' id -> (split, tile) map (hgemm_kernel.hpp raster_ref = map_logical) against its multiply-shift
+    form, on the host, for every id of many launch shapes (plain, split-K, hybrid tail), and the map itself: every
+    (split, tile row, tile column) is produced exactly once."""
+    f = lib.hgemm_mi355x_selfcheck_raster
+    f.argtypes = [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_int * 4)]
+    out_r, out_f = (ctypes.c_int * 4)(), (ctypes.c_int * 4)()
+    cases = []
+    for tm, tn in [(1, 1), (1, 64), (64, 1), (2, 3), (7, 5), (16, 16), (17, 17), (33, 9), (9, 33), (64, 48), (3, 128), (128, 2)]:
+        for g in (1, 2, 3, 4, 5, 8, 16, 32, 64, 1000):
+            if g > tm and g != 1000:
+                continue
+            for splits in (1, 2, 5):
+                cases.append((tm, tn, min(g, tm), 0, 0, splits))
+    cases += [(17, 17, 4, 256, 33, 7), (28, 28, 8, 768, 16, 16), (5, 9, 2, 40, 5, 3), (64, 64, 4, 4095, 1, 31)]   # hybrid tail passes
+    for tm, tn, g, tail_first, tail_tiles, splits in cases:
+        per = tail_tiles if tail_tiles else tm * tn
+        seen = set()
+        for bid in range(per * splits):
+            assert f(tm, tn, g, tail_first, tail_tiles, bid, 0, ctypes.byref(out_r)) == 0
+            assert f(tm, tn, g, tail_first, tail_tiles, bid, 1, ctypes.byref(out_f)) == 0
+            assert list(out_r) == list(out_f), (tm, tn, g, tail_first, tail_tiles, bid, list(out_r), list(out_f))
+            split, tile, im, jn = out_r
+            assert 0 <= split < splits and 0 <= im < tm and 0 <= jn < tn
+            assert tail_first <= tile < tail_first + per if tail_tiles else 0 <= tile < per
+            seen.add((split, im, jn))
+        assert len(seen) == per * splits
