@@ -67,7 +67,9 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)
  * (reference kernels/a100_F32F16F16F32/64_4096_64.cu:275-287) and cuda_l2_<dev>_fp16
  * (kernels/a100_F16F16F16F16/4096_4096_4096.cu:280-295).  Picks the tuned kernel geometry /
- * split-K plan for (M,N,K) (tuned table first, analytic model otherwise) and launches it.
+ * split-K plan for (M,N,K) and launches it: the tuned table for the 1000 grid shapes; for any other shape the
+ * tuned plans of the grid shapes around it, ranked by the analytic model (the model alone when none of them fits);
+ * off-grid plans are remembered per thread, so a repeated shape costs one table probe.
  * Any M,N,K >= 1 is accepted; shapes the LDS-DMA kernels cannot take (K % 8 != 0, N % 4 != 0,
  * pointers or strides not 16-byte aligned, operands beyond 32-bit tile offsets) run on a register-staged
  * MFMA kernel that pads on the way into LDS (the reference pads in the harness, tools/utils.py:8-36).

@@ -401,3 +401,43 @@ def test_raster_map_fast_equals_reference_and_is_a_bijection(lib):
             assert tail_first <= tile < tail_first + per if tail_tiles else 0 <= tile < per
             seen.add((split, im, jn))
         assert len(seen) == per * splits
+
+
+def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
+    """A shape outside the tuned table takes one of the tuned plans of the lattice corners around it (ranked by the
+    analytic model), falls back to the model when no corner plan fits (K % 64 != 0: only the K-tail family), is
+    remembered per thread (same answer on every call and from another thread), and never disturbs grid shapes."""
+    import threading
+
+    def plan(m, n, k):
+        c, s, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.hgemm_mi355x_plan(m, n, k, ctypes.byref(c), ctypes.byref(s), ctypes.byref(g)) == 0
+        return c.value, s.value, g.value
+
+    lattice = [64, 128, 256, 512, 1024, 2048, 4096, 8192, 12288, 16384]
+
+    def bracket(x):
+        lo = max([v for v in lattice if v <= x] or [lattice[0]])
+        hi = min([v for v in lattice if v >= x] or [lattice[-1]])
+        return lo, hi
+
+    for m, n, k in [(5000, 3000, 7040), (6144, 6144, 6144), (4096, 11008, 4096), (8192, 28672, 4096), (100, 200, 320), (20000, 20000, 512),
+                    (48, 4096, 64), (3000, 4096, 128)]:
+        cfg, splits, group = plan(m, n, k)
+        corners = {plan(a, b, c)[0] for a in bracket(m) for b in bracket(n) for c in bracket(k)}
+        assert cfg in corners, (m, n, k, lib.hgemm_mi355x_config_name(cfg))
+        assert k % lib.hgemm_mi355x_config_k_granularity(cfg) == 0
+        assert 1 <= (splits & 0xFFFF) <= max(1, k // 64) and group >= 1
+        assert plan(m, n, k) == (cfg, splits, group)
+        other = []
+        t = threading.Thread(target=lambda: other.append(plan(m, n, k)))
+        t.start(); t.join()
+        assert other == [(cfg, splits, group)]
+    # K % 64 != 0: the persistent families' plans do not fit, whatever is chosen must accept the K tail
+    cfg, splits, _ = plan(4000, 4000, 4000)
+    assert lib.hgemm_mi355x_config_k_granularity(cfg) == 8 and lib.hgemm_mi355x_config_name(cfg).decode().startswith("t")
+    # 33 distinct off-grid shapes map onto 32 memo slots: evictions must not change any answer
+    shapes = [(1000 + 8 * i, 520, 704) for i in range(33)]
+    first = [plan(*s) for s in shapes]
+    assert [plan(*s) for s in shapes] == first
+    assert plan(4096, 4096, 4096)[0] == lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
