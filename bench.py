@@ -53,7 +53,8 @@ EVENT_STRIDE = 16              # every 16th launch of the timed region carries d
 
 def load_library():
     """The product path: libhgemm_mi355x.so through its C ABI.  No fallback of any kind."""
-    so = PKG / "lib" / "libhgemm_mi355x.so"
+    # (HGEMM_LIB_DIR: an experiment build of the same library, cuda-l2_amd/lib_<suffix>/, for A/B runs of the tools)
+    so = Path(os.environ.get("HGEMM_LIB_DIR", PKG / "lib")) / "libhgemm_mi355x.so"
     if not so.exists():
         raise RuntimeError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
     lib = ctypes.CDLL(str(so))
