@@ -16,7 +16,7 @@ using namespace hgemm_mi355x;
 
 namespace {
 
-int g_last_hip_error = 0;
+thread_local int g_last_hip_error = 0;   // per calling thread, like hipGetLastError (calls may come from any thread)
 #ifdef HGEMM_ABLATION
 int g_debug_flags = 0;  // tuner-only build: hgemm_mi355x_set_debug
 #endif

@@ -141,7 +141,7 @@ int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream);
 int hgemm_mi355x_release_workspaces(void);
 
 const char* hgemm_mi355x_strerror(int status);
-int hgemm_mi355x_last_hip_error(void);
+int hgemm_mi355x_last_hip_error(void);   /* hipError_t behind the calling thread's last HGEMM_ERR_HIP */
 const char* hgemm_mi355x_version(void);
 
 /* ------------------------------------------------------------------------------------------
