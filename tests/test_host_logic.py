@@ -441,3 +441,26 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
     first = [plan(*s) for s in shapes]
     assert [plan(*s) for s in shapes] == first
     assert plan(4096, 4096, 4096)[0] == lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
+
+
+def test_planner_fuzz_every_answer_is_launchable(lib):
+    """Random shapes (aligned and not): the planner always answers with a geometry whose K granularity divides K (or
+    a special id), a split count a launch would accept, and a raster group >= 1."""
+    import random
+
+    rnd = random.Random(11)
+    n_cfg = lib.hgemm_mi355x_num_configs()
+    c, s, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for _ in range(600):
+        m = rnd.choice([1, 7, 48, 64, 100, 333, 1000, 4096, 5000, 12288, 20000, 70000])
+        n = rnd.choice([4, 12, 64, 136, 200, 520, 4096, 11008, 28672, 16384]) + rnd.choice([0, 0, 0, 1, 2])
+        k = rnd.choice([8, 40, 64, 72, 128, 200, 320, 1024, 4000, 4096, 7040, 16384, 20480]) + rnd.choice([0, 0, 0, 4, 1])
+        assert lib.hgemm_mi355x_plan(m, n, k, ctypes.byref(c), ctypes.byref(s), ctypes.byref(g)) == 0
+        if k % 8 or n % 4:
+            assert c.value == -2 and s.value == 1          # HGEMM_CONFIG_RAGGED
+            continue
+        assert 0 <= c.value < n_cfg, (m, n, k, c.value)
+        gran = lib.hgemm_mi355x_config_k_granularity(c.value)
+        assert k % gran == 0, (m, n, k, lib.hgemm_mi355x_config_name(c.value), gran)
+        assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x1FFFF) == 0 and g.value >= 1
+        assert not lib.hgemm_mi355x_config_name(c.value).decode().endswith("_m32") or lib.hgemm_mi355x_config_name(c.value).decode().startswith("t")
