@@ -8,6 +8,9 @@ set -u
 O=gpurun_out/r3a; mkdir -p $O
 T=cuda-l2_amd/bin/hgemm_tune
 timeout 400 python -m pytest tests -m gpu -q 2>&1 | tail -5
+# off-grid shapes at the plans the neighbour planner gives them: parity against the oracle, then device time against the vendor libraries
+timeout 300 python tests/tools/verify_plans.py --shape-file cuda-l2_amd/tools/offgrid_shapes.txt --out $O/parity_offgrid.jsonl | tail -1
+timeout 300 $T tune --plan-only --baselines --shape-file cuda-l2_amd/tools/offgrid_shapes.txt --out $O/offgrid_plan_report.jsonl > $O/offgrid_plan_report.log 2>&1; tail -2 $O/offgrid_plan_report.log
 if [ -f cuda-l2_amd/lib_fd/libhgemm_mi355x.so ]; then
   LD_LIBRARY_PATH=$PWD/cuda-l2_amd/lib_fd timeout 120 $T check --shapes 328_456_1024,4352_4352_320,512_768_128,256_256_8192 | tail -3
   HGEMM_LIB_DIR=$PWD/cuda-l2_amd/lib_fd timeout 300 python tests/tools/verify_plans.py --out $O/parity_fastdiv.jsonl | tail -1

@@ -91,7 +91,8 @@ def main(argv=None) -> int:
     if a.shapes:
         shapes = [tuple(int(x) for x in s.split("_")) for s in a.shapes.split(",") if s]
     else:
-        shapes = [tuple(int(x) for x in ln.split("_")) for ln in Path(a.shape_file).read_text().split() if ln]
+        shapes = [tuple(int(x) for x in ln.split("_")) for ln in (raw.strip() for raw in Path(a.shape_file).read_text().splitlines())
+                  if ln and not ln.startswith("#")]
     cand = {}
     if a.plans:
         for ln in Path(a.plans).read_text().splitlines():
