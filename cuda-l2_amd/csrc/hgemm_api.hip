@@ -20,6 +20,14 @@ thread_local int g_last_hip_error = 0;   // per calling thread, like hipGetLastE
 #ifdef HGEMM_ABLATION
 int g_debug_flags = 0;  // tuner-only build: hgemm_mi355x_set_debug
 #endif
+#ifdef HGEMM_TIMELINE
+// measurement build (lib_tl/): hgemm_mi355x_set_timeline lends a device buffer of `slots` records, launch n writes record
+// n % slots (kTimelineWgs workgroups x HGEMM_TL_WORDS words each)
+unsigned long long* g_timeline = nullptr;
+int g_timeline_slots = 0;
+unsigned g_timeline_count = 0;
+constexpr int kTimelineWgs = 1024;
+#endif
 
 // ---- split-K workspace ------------------------------------------------------------------------
 // One buffer per (device, stream): two GEMMs on different streams (or devices) never share slabs or
@@ -413,6 +421,11 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
 #ifdef HGEMM_ABLATION
   g.debug = g_debug_flags;
 #endif
+#ifdef HGEMM_TIMELINE
+  g.timeline = (g_timeline && g_timeline_slots > 0)
+                   ? g_timeline + (size_t)(g_timeline_count++ % (unsigned)g_timeline_slots) * kTimelineWgs * HGEMM_TL_WORDS
+                   : nullptr;
+#endif
 
   bool fast = config_id >= 0 && b_col_major && mfma_path_ok(a, b_col_major, c, M, N, K, lda, ldb, ldc);
   if (fast) {
@@ -584,6 +597,18 @@ double hgemm_mi355x_event_elapsed_us(void* start_event, void* stop_event) {
 #ifdef HGEMM_ABLATION
 // tuner-only library build (lib_ablation/): results are garbage by construction, never shipped
 int hgemm_mi355x_set_debug(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
+#endif
+
+#ifdef HGEMM_TIMELINE
+// measurement library build (lib_tl/), never shipped: see HGEMM_TL_* in hgemm_kernel.hpp.  The buffer must hold
+// slots * 1024 * 16 eight-byte words; returns the number of launches recorded so far.
+int hgemm_mi355x_set_timeline(void* device_ptr, int slots) {
+  g_timeline = (unsigned long long*)device_ptr;
+  g_timeline_slots = device_ptr ? slots : 0;
+  const int n = (int)g_timeline_count;
+  g_timeline_count = 0;
+  return n;
+}
 #endif
 
 const char* hgemm_mi355x_version(void) { return "hgemm_mi355x 0.2 (gfx950)"; }

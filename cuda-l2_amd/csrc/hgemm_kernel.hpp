@@ -154,7 +154,41 @@ struct GemmArgs {
   int debug;       // tuner-only build (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
                    // epilogue stores, bit 2 cut every tile's K loop to two steps, bit 3 every tile stores to tile (0,0)
 #endif
+#ifdef HGEMM_TIMELINE
+  unsigned long long* timeline;   // measurement build (lib_tl/): 16 words per workgroup, see HGEMM_TL_* below; may be null
+#endif
 };
+
+// Measurement build only (-DHGEMM_TIMELINE, lib_tl/; hgemm_tune bench --timeline): wave 0 of every workgroup stamps the
+// shader clock (s_memtime) at the seams of the kernel -- entry, pipeline primed, last MFMA of the last work item, last
+// store issued, stores acknowledged -- and the 100 MHz wall clock (s_memrealtime) at entry and exit, so the head / K loop /
+// epilogue / drain split of a launch and the gap between back-to-back launches can be read per workgroup.
+#ifdef HGEMM_TIMELINE
+#define HGEMM_TL_WORDS 16
+// stamp -> 8-byte slot `slot` of the kernel's LDS scratch (lane 0 of wave 0 only): no SGPRs stay live across the K loop.
+// The LDS accesses are written as asm on the 32-bit LDS address: a volatile C++ store through the generic pointer
+// becomes a flat store with a vmcnt(0) behind it, which would drain the LDS-DMA pipeline at every stamp.
+#define HGEMM_TL_PUT_(INSTR, slots, slot, tid)                                                            \
+  do {                                                                                                    \
+    unsigned long long v_;                                                                                \
+    asm volatile(INSTR " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_) :: "memory");                            \
+    if ((tid) == 0) {                                                                                     \
+      const unsigned a_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(slots) + 8u * (slot); \
+      asm volatile("ds_write_b64 %0, %1" :: "v"(a_), "v"(v_) : "memory");                                 \
+    }                                                                                                     \
+  } while (0)
+#define HGEMM_TL_STAMP(slots, slot, tid) HGEMM_TL_PUT_("s_memtime", slots, slot, tid)
+#define HGEMM_TL_REALTIME(slots, slot, tid) HGEMM_TL_PUT_("s_memrealtime", slots, slot, tid)
+__device__ __forceinline__ unsigned long long hgemm_tl_get(const char* slots, int slot) {
+  unsigned long long v;
+  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(slots) + 8u * slot;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+  return v;
+}
+#else
+#define HGEMM_TL_STAMP(slots, slot, tid) ((void)0)
+#define HGEMM_TL_REALTIME(slots, slot, tid) ((void)0)
+#endif
 inline void set_raster_div(GemmArgs& g) {   // host: after tiles_m / tiles_n / group_m / tail_tiles are final
 #if HGEMM_FASTDIV
   g.rd = make_raster_div(g.tiles_m, g.tiles_n, g.group_m, g.tail_tiles);

@@ -51,6 +51,11 @@
 #ifndef HGEMM_SQ_QORDER
 #define HGEMM_SQ_QORDER 0     // behind Q: 0 = B-fragment reads lead the A pieces, 1 = the pieces lead
 #endif
+#ifndef HGEMM_SQ_ABL
+#define HGEMM_SQ_ABL 0        // measurement builds only (results are garbage): drop parts of the K loop to price them with the
+                              // timeline stamps: 1 no s_barrier, 2 no vmcnt wait, 4 no lgkmcnt(0) at the sync points,
+                              // 8 no LDS-DMA pieces, 16 no fragment reads
+#endif
 
 namespace hgemm_mi355x {
 
@@ -158,21 +163,21 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       // every fragment read of the region about to be refilled has RETURNED (LDS returns in order, and the
       // leading reads were the last ones issued), and my pieces of the half-tile the trailing reads are
       // about to consume have landed; two younger half-tiles may stay in flight
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<CFG::NJA + CFG::NJB>();
-      sp_sync();
+      if (!(HGEMM_SQ_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(HGEMM_SQ_ABL & 2)) wait_vmcnt<CFG::NJA + CFG::NJB>();
+      if (!(HGEMM_SQ_ABL & 1)) sp_sync();
     }
     sp_mfma_mi<CFG::MI>(i * FN + j, bf[u * FN + j], af[u * FM + i]);
-    if (n % RS == 0 && n / RS < NLEAD) {
+    if (!(HGEMM_SQ_ABL & 16) && n % RS == 0 && n / RS < NLEAD) {
       const int r = n / RS;
       lead[r] = *(const f16x8*)((r / FLEAD ? lead1 : lead0) + (r % FLEAD) * CFG::MI * ROW_BYTES);
     }
     if (PHASE == 0) {
-      const int r = PL::a_read_at(n), p = PL::a_piece_at(n);
+      const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::a_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::a_piece_at(n);
       if (p >= 0) sq_issue_piece<CFG, 1>(rs, voff, dma_stage, wave, p, kbyte);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
     } else {
-      const int r = PL::b_read_at(n), p = PL::b_piece_at(n);
+      const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::b_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::b_piece_at(n);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
       if (p >= 0) sq_issue_piece<CFG, 0>(rs, voff, dma_stage, wave, p, kbyte);
     }
@@ -265,6 +270,10 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
 
   const int tid  = threadIdx.x;
+  // (measurement build: stamps go to the 64 scratch bytes behind the stages; slot 0 doubles as the fused vote word,
+  // so the timeline is only meaningful for the plain epilogues)
+  HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 0, tid);
+  HGEMM_TL_REALTIME(smem + CFG::LDS_BYTES, 1, tid);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / CFG::WN;
@@ -326,10 +335,12 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   SQ_ADVANCE(0);
 
   int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
+  HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 2, tid);
 #pragma clang loop unroll(disable)
   for (int item = 0; item < walk.count; ++item) {
     const TileCoord tc = map_logical(g, walk.base + walk.first + item * walk.stride, BM, BN);
     const int nk = __builtin_amdgcn_readfirstlane(tc.nk / CFG::KT);
+    HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 3, tid);
     // hot loop, two K-steps per trip: both streams stay inside this work item (the A stream issues tile t+3
     // in K-step t and is then moved on: the trip's last move must stay inside the item, t + 5 < nk), so moving
     // them on is a scalar add
@@ -356,6 +367,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       for (int r = 0; r < NFA; ++r) fY[r] = fZ[r];
     }
     // ---- epilogue of this work item (as family "s"): unit by unit (MI = 16: one fragment row, MI = 32: one tile) ---
+    HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 4, tid);
     sp_mfma_drain();
     const bool rezero = item + 1 < walk.count;
     const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
@@ -442,8 +454,23 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 5, tid);
   }
   wait_vmcnt<0>();  // redundant tail pieces must not outlive the workgroup's LDS allocation
+#ifdef HGEMM_TIMELINE
+  HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 6, tid);
+  HGEMM_TL_REALTIME(smem + CFG::LDS_BYTES, 7, tid);
+  if (g.timeline != nullptr && tid == 0) {
+    // words 0..7: entry, entry (100 MHz clock), pipeline primed, last item's loop start, its last MFMA, its last store
+    // issued, everything acknowledged, exit (100 MHz clock); 8: XCC id << 32 | HW_ID; 9: K-steps walked; 10: work items
+    unsigned long long* tl = g.timeline + (size_t)blockIdx.x * HGEMM_TL_WORDS;
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tl[w] = hgemm_tl_get(smem + CFG::LDS_BYTES, w);
+    tl[8] = ((unsigned long long)xcc << 32) | hw; tl[9] = (unsigned long long)step; tl[10] = (unsigned long long)walk.count;
+  }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -7,6 +7,8 @@
 //                                                     time candidate plans, print one JSON line per shape
 //   hgemm_tune bench --shape M_N_K [--config NAME --splits S --group G] [--reps N] [--lib]
 //                                                     run one plan N times (for rocprofv3)
+//   hgemm_tune bench --shape M_N_K --baseline X --isolated [--reps N]   a vendor baseline one launch at a time (for rocprofv3 --pmc)
+//   hgemm_tune bench --shape M_N_K --timeline [...]   (measurement library lib_tl/ only) in-kernel clock stamps of back-to-back launches
 //   hgemm_tune bench --shape M_N_K --power [--seconds S] [--baseline hipblaslt_tn|hipblaslt_nn|rocblas_tn] [...]
 //                                                     back-to-back launches for S seconds (no sync in between); reports
 //                                                     us per call and the board's gfx clock / socket power sampled over
@@ -26,6 +28,7 @@
 #include <cstring>
 #include <cstdint>
 #include <fstream>
+#include <functional>
 #include <sstream>
 #include <atomic>
 #include <chrono>
@@ -40,6 +43,8 @@
 // Ablation switches exist only in the -DHGEMM_ABLATION build of the library (build.py: HGEMM_LIB_SUFFIX=ablation
 // HGEMM_EXTRA_HIPFLAGS=-DHGEMM_ABLATION); against the shipping library the symbol is absent and --debug refuses.
 extern "C" int hgemm_mi355x_set_debug(int flags) __attribute__((weak));
+// Timeline stamps exist only in the -DHGEMM_TIMELINE build (lib_tl/); bench --timeline refuses without it.
+extern "C" int hgemm_mi355x_set_timeline(void* device_ptr, int slots) __attribute__((weak));
 
 #define HIP_OK(x)                                                                         \
   do {                                                                                    \
@@ -522,6 +527,74 @@ static int power_bench(const Shape& sh, const char* label, F&& launch, std::vect
   return 0;
 }
 
+// bench --timeline (measurement library lib_tl/ only): N back-to-back launches with the in-kernel stamps on, then the
+// head / K-loop / epilogue / drain split per workgroup (shader cycles), the kernel's own clock estimate (stamps against
+// the 100 MHz wall clock) and the gap between consecutive launches per XCD.
+static bool g_timeline = false;
+template <class F>
+static int timeline_bench(const Shape& sh, const char* label, F&& launch, std::vector<Buffers>& sets) {
+  if (!hgemm_mi355x_set_timeline) { fprintf(stderr, "--timeline needs the -DHGEMM_TIMELINE library build (lib_tl/)\n"); return 2; }
+  constexpr int kSlots = 8, kWgs = 1024, kWords = 16;
+  unsigned long long* dev = nullptr;
+  const size_t bytes = (size_t)kSlots * kWgs * kWords * 8;
+  HIP_OK(hipMalloc(&dev, bytes));
+  for (int i = 0; i < 200; ++i) (void)launch(sets[i % sets.size()]);   // warm: clocks at their steady state
+  HIP_OK(hipMemset(dev, 0, bytes));
+  HIP_OK(hipDeviceSynchronize());
+  for (int i = 0; i < 50; ++i) (void)launch(sets[i % sets.size()]);
+  hgemm_mi355x_set_timeline(dev, kSlots);
+  for (int i = 0; i < kSlots; ++i)
+    if (launch(sets[i % sets.size()]) != HGEMM_OK) { fprintf(stderr, "timeline: launch failed\n"); return 1; }
+  hgemm_mi355x_set_timeline(nullptr, 0);
+  for (int i = 0; i < 8; ++i) (void)launch(sets[i % sets.size()]);      // the recorded launches are not the stream's last
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)kSlots * kWgs * kWords);
+  HIP_OK(hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost));
+  HIP_OK(hipFree(dev));
+  auto q = [](std::vector<double> v, double f) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+  unsigned long long prev_end[8] = {0}, prev_rend = 0;
+  for (int sl = 0; sl < kSlots; ++sl) {
+    std::vector<double> head, loop, epi, drain, total, mhz, step_cyc;
+    unsigned long long first[8], last[8], rfirst = ~0ull, rlast = 0;
+    for (int x = 0; x < 8; ++x) { first[x] = ~0ull; last[x] = 0; }
+    int wgs = 0, items = 0;
+    for (int w = 0; w < kWgs; ++w) {
+      const unsigned long long* t = &h[((size_t)sl * kWgs + w) * kWords];
+      if (t[0] == 0 || t[6] == 0) continue;
+      ++wgs;
+      const int xcc = (int)((t[8] >> 32) & 7);
+      head.push_back((double)(t[2] - t[0])); loop.push_back((double)(t[4] - t[3])); epi.push_back((double)(t[5] - t[4]));
+      drain.push_back((double)(t[6] - t[5])); total.push_back((double)(t[6] - t[0]));
+      if (t[7] > t[1]) mhz.push_back((double)(t[6] - t[0]) / ((double)(t[7] - t[1]) * 0.01));   // cycles per us
+      const double it = (double)t[10] > 0 ? (double)t[9] / (double)t[10] : 0;   // K-steps of one item
+      if (it > 0) step_cyc.push_back((double)(t[4] - t[3]) / it);
+      items += (int)t[10];
+      first[xcc] = std::min(first[xcc], t[0]); last[xcc] = std::max(last[xcc], t[6]);
+      rfirst = std::min(rfirst, t[1]); rlast = std::max(rlast, t[7]);
+    }
+    std::vector<double> gap, span;
+    for (int x = 0; x < 8; ++x) {
+      if (last[x] == 0) continue;
+      span.push_back((double)(last[x] - first[x]));
+      if (sl > 0 && prev_end[x] != 0) gap.push_back((double)first[x] - (double)prev_end[x]);
+      prev_end[x] = last[x];
+    }
+    printf("{\"mnk\": \"%d_%d_%d\", \"what\": \"%s\", \"mode\": \"timeline\", \"launch\": %d, \"wgs\": %d, \"items\": %d, "
+           "\"wall_us\": %.2f, \"gap_wall_us\": %.2f, \"mhz_med\": %.0f, "
+           "\"cycles\": {\"head\": [%.0f, %.0f, %.0f], \"loop_last_item\": [%.0f, %.0f, %.0f], \"per_k_step\": [%.0f, %.0f, %.0f], "
+           "\"epilogue\": [%.0f, %.0f, %.0f], \"drain\": [%.0f, %.0f, %.0f], \"wg_total\": [%.0f, %.0f, %.0f], "
+           "\"xcd_span\": [%.0f, %.0f, %.0f], \"xcd_gap_to_prev\": [%.0f, %.0f, %.0f]}}\n",
+           sh.M, sh.N, sh.K, label, sl, wgs, items, (double)(rlast - rfirst) * 0.01,
+           sl > 0 && prev_rend ? ((double)rfirst - (double)prev_rend) * 0.01 : 0.0, q(mhz, 0.5),
+           q(head, 0.1), q(head, 0.5), q(head, 0.9), q(loop, 0.1), q(loop, 0.5), q(loop, 0.9), q(step_cyc, 0.1), q(step_cyc, 0.5), q(step_cyc, 0.9),
+           q(epi, 0.1), q(epi, 0.5), q(epi, 0.9), q(drain, 0.1), q(drain, 0.5), q(drain, 0.9), q(total, 0.1), q(total, 0.5), q(total, 0.9),
+           q(span, 0.0), q(span, 0.5), q(span, 1.0), q(gap, 0.0), q(gap, 0.5), q(gap, 1.0));
+    prev_rend = rlast;
+  }
+  fflush(stdout);
+  return 0;
+}
+
 static const char* g_baseline = nullptr;   // bench --baseline
 static bool g_power = false;               // bench --power
 static double g_seconds = 1.5;             // bench --seconds
@@ -549,19 +622,30 @@ static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int grou
   if (g_baseline) {
     const std::string b = g_baseline;
     int rc = 0;
+    std::function<int(Buffers&)> base;
     if (b == "rocblas_tn") {
       hgemm_rocblas_init();
-      rc = power_bench(sh, g_baseline, [&](Buffers& s) { return hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, g_seconds);
+      base = [&](Buffers& s) { return hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); };
     } else if (b == "hipblaslt_tn" || b == "hipblaslt_nn") {
       hgemm_hipblaslt_heuristic_init();
       const bool tn = b == "hipblaslt_tn";
-      rc = power_bench(sh, g_baseline, [&](Buffers& s) {
+      base = [&, tn](Buffers& s) {
         return tn ? hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr)
-                  : hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, g_seconds);
+                  : hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); };
     } else {
       fprintf(stderr, "unknown --baseline %s\n", g_baseline);
       rc = 2;
     }
+    if (rc == 0 && g_power) rc = power_bench(sh, g_baseline, base, sets, g_seconds);
+    else if (rc == 0) {   // --isolated: one launch at a time, `reps` of them (the form a rocprofv3 --pmc pass can afford)
+      const double us = time_us(base, sets, 3, reps, e0, e1);
+      printf("{\"mnk\": \"%d_%d_%d\", \"what\": \"%s\", \"mode\": \"isolated\", \"us\": %.3f, \"reps\": %d}\n", sh.M, sh.N, sh.K, g_baseline, us, reps);
+    }
+    for (auto& s : sets) free_set(s);
+    return rc;
+  }
+  if (g_timeline) {
+    const int rc = timeline_bench(sh, cfg >= 0 ? hgemm_mi355x_config_name(cfg) : "generic", launch, sets);
     for (auto& s : sets) free_set(s);
     return rc;
   }
@@ -590,7 +674,7 @@ int main(int argc, char** argv) {
   const char* cfg_name = nullptr;
   double keep = 2.5;
   int max_cand = 12, splits = 1, group = 0, reps = 20;
-  bool baselines = false, use_lib = false, sweep_group = false, autotune = false;
+  bool baselines = false, use_lib = false, sweep_group = false, autotune = false, isolated = false;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
@@ -611,6 +695,8 @@ int main(int argc, char** argv) {
     else if (a == "--reps") reps = atoi(next());
     else if (a == "--lib") use_lib = true;
     else if (a == "--power") g_power = true;
+    else if (a == "--timeline") g_timeline = true;
+    else if (a == "--isolated") isolated = true;
     else if (a == "--seconds") g_seconds = atof(next());
     else if (a == "--baseline") { g_baseline = next(); g_power = true; }
     else if (a == "--ld") g_ld_override = atoi(next());
@@ -638,6 +724,7 @@ int main(int argc, char** argv) {
   }
   if (mode == "bench") {
     if (shapes.empty()) { fprintf(stderr, "bench needs --shape\n"); return 2; }
+    if (isolated) g_power = false;
     int rc = 0;
     for (const Shape& sh : shapes) rc |= cmd_bench(sh, cfg_name, splits, group, reps, use_lib);
     return rc;
