@@ -84,6 +84,17 @@ int ensure_workspace(size_t slab_bytes, hipStream_t stream, float** slabs, unsig
     w->captured = true;
   }
   if (need > w->bytes) {
+    // hipMalloc / hipFree are "unsafe" calls for stream capture: made while ANOTHER stream of the process captures in
+    // global mode (this call's own stream does not, see above; the legacy stream cannot even be asked) they would
+    // invalidate that capture.  The thread's capture mode is switched to relaxed around them, which is the documented
+    // way for a library to allocate next to somebody else's capture.
+    struct RelaxedCapture {
+      hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+      bool ok;
+      RelaxedCapture() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+      ~RelaxedCapture() { if (ok && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+    } relaxed;
+    const size_t old = w->bytes;   // (read before the buffer is let go: the growth below is geometric in the OLD size)
     if (w->ptr && w->captured) {
       g_ws_retired.push_back(w->ptr);
       w->ptr = nullptr; w->bytes = 0; w->captured = false;
@@ -92,8 +103,9 @@ int ensure_workspace(size_t slab_bytes, hipStream_t stream, float** slabs, unsig
       if (e != hipSuccess) { g_last_hip_error = (int)e; return HGEMM_ERR_HIP; }
       w->ptr = nullptr; w->bytes = 0;
     }
-    // Grow geometrically (min 64 MiB) so a sweep over shapes re-allocates O(log) times.
-    const size_t want = std::max(need, std::max<size_t>(w->bytes * 2, (size_t)64 << 20));
+    // Grow geometrically (first buffer: at least 8 MiB) so a sweep over shapes re-allocates O(log) times, while a
+    // process with many short-lived streams does not pin 64 MiB for each of them (round 2 did).
+    const size_t want = std::max(need, std::max<size_t>(old * 2, (size_t)8 << 20));
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { (void)hipGetLastError(); g_last_hip_error = (int)e; return HGEMM_ERR_NO_WORKSPACE_INTERNAL; }
@@ -112,11 +124,14 @@ const TunedRow g_tuned_rows[] = {
 #include "hgemm_tuned_table.inc"
     {0, 0, 0, nullptr, 0, 0}};
 
-struct TunedPlan { uint64_t key; int cfg, splits, group_m; };
+struct TunedPlan { uint64_t key; int M, N, K; int cfg, splits, group_m; };   // key orders the index; M, N, K decide a hit
 TunedPlan* g_tuned = nullptr;
 int g_num_tuned = 0;
 std::once_flag g_tuned_once;
 
+// Sort / hash key only: the three fields overlap once a dimension reaches 2^21, so two shapes may share a key --
+// every probe below compares M, N, K themselves (round 2 compared the key alone: plan(64, 68, 8388864) returned
+// the tuned row of (64, 64, 256)).
 inline uint64_t shape_key(int M, int N, int K) {
   return ((uint64_t)(uint32_t)M << 42) ^ ((uint64_t)(uint32_t)N << 21) ^ (uint64_t)(uint32_t)K;
 }
@@ -127,8 +142,8 @@ void build_tuned_index() {
   for (int i = 0; i < rows; ++i) {
     const int id = hgemm_mi355x_config_by_name(g_tuned_rows[i].cfg);
     if (id < 0) continue;  // stale row (geometry removed): fall back to the model
-    g_tuned[g_num_tuned++] = {shape_key(g_tuned_rows[i].M, g_tuned_rows[i].N, g_tuned_rows[i].K), id,
-                              g_tuned_rows[i].splits, g_tuned_rows[i].group_m};
+    g_tuned[g_num_tuned++] = {shape_key(g_tuned_rows[i].M, g_tuned_rows[i].N, g_tuned_rows[i].K), g_tuned_rows[i].M,
+                              g_tuned_rows[i].N, g_tuned_rows[i].K, id, g_tuned_rows[i].splits, g_tuned_rows[i].group_m};
   }
   std::sort(g_tuned, g_tuned + g_num_tuned,
             [](const TunedPlan& a, const TunedPlan& b) { return a.key < b.key; });
@@ -233,7 +248,9 @@ const TunedPlan* find_tuned(int M, int N, int K) {
   const uint64_t key = shape_key(M, N, K);
   const TunedPlan* lo = std::lower_bound(g_tuned, g_tuned + g_num_tuned, key,
                                          [](const TunedPlan& p, uint64_t k) { return p.key < k; });
-  return (lo != g_tuned + g_num_tuned && lo->key == key) ? lo : nullptr;
+  for (; lo != g_tuned + g_num_tuned && lo->key == key; ++lo)
+    if (lo->M == M && lo->N == N && lo->K == K) return lo;
+  return nullptr;
 }
 
 bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
@@ -270,7 +287,7 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
 
 // Plans of off-grid shapes are remembered per thread (the search above / model_plan cost 3-7 us of host time, as much
 // as a launch-bound GEMM itself; a harness calls the same shape over and over).
-struct PlanMemo { uint64_t key; int cfg, splits, group_m; };
+struct PlanMemo { int M, N, K; int cfg, splits, group_m; };
 thread_local PlanMemo t_plan_memo[32] = {};
 
 // alignment rules of the LDS-DMA path (the K multiple depends on the geometry: k_ok())
@@ -333,10 +350,10 @@ int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* gro
     *config_id = HGEMM_CONFIG_RAGGED; *splits = 1; *group_m = 1;
     return HGEMM_OK;
   }
-  const uint64_t key = shape_key(M, N, K);   // (never 0 here: M, N, K >= 1)
+  const uint64_t key = shape_key(M, N, K);
   PlanMemo& memo = t_plan_memo[(key ^ (key >> 21) ^ (key >> 42)) & 31];
-  if (memo.key != key) {
-    PlanMemo m{key, 0, 1, 1};
+  if (memo.M != M || memo.N != N || memo.K != K) {   // (an empty slot holds M = 0, never a valid shape)
+    PlanMemo m{M, N, K, 0, 1, 1};
     if (!neighbour_plan(M, N, K, &m.cfg, &m.splits, &m.group_m)) model_plan(M, N, K, &m.cfg, &m.splits, &m.group_m);
     memo = m;
   }
@@ -388,6 +405,23 @@ int hgemm_mi355x_release_workspaces(void) {
   return rc;
 }
 
+int hgemm_mi355x_release_stream_workspace(void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return HGEMM_ERR_HIP;
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  for (size_t i = 0; i < g_ws.size(); ++i) {
+    if (g_ws[i].device != dev || g_ws[i].stream != (hipStream_t)stream) continue;
+    int rc = HGEMM_OK;
+    if (g_ws[i].ptr) {
+      if (g_ws[i].captured) g_ws_retired.push_back(g_ws[i].ptr);   // a graph may still hold it: lives until release_workspaces
+      else if (hipFree(g_ws[i].ptr) != hipSuccess) rc = HGEMM_ERR_HIP;
+    }
+    g_ws.erase(g_ws.begin() + (long)i);
+    return rc;
+  }
+  return HGEMM_OK;
+}
+
 int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
   int cfg = 0, splits = 1, group = 1;
@@ -435,6 +469,8 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     const double reach = e.ktail ? 2147483648.0 : 4294967296.0;   // (the classic family keeps bit 31 as its out-of-range mark)
     if ((double)e.bm * lda * 2.0 + K * 2.0 >= reach || (double)e.bn * ldb * 2.0 + K * 2.0 >= reach) fast = false;
     if (K % BK != 0 && !e.ktail) fast = false;   // a partial last K-step on a geometry that cannot pad it: any-shape kernel
+    // the LDS-staged epilogue addresses a wave tile through one buffer descriptor with 32-bit offsets
+    if ((double)e.bm * ldc * 2.0 + (double)N * 2.0 >= 2147483648.0) fast = false;
   }
   if (!fast) {
     if (config_id != HGEMM_CONFIG_GENERIC && b_col_major) {

@@ -313,6 +313,102 @@ __device__ __forceinline__ void sp_store_tile32(const GemmArgs& g, int m, int nb
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
+// ---- LDS-staged fp16 epilogue (round 3) -----------------------------------------------------------------------------
+// Timeline of the round-2 epilogue (tools/gpu_round3_a.sh): ~8.3-9k cycles per 256x256 tile wherever it runs (alone at the
+// end of a single-round grid or between the K loops of a persistent walk), i.e. ~16 B/clk/CU: it is bound by the store
+// instruction, not by bandwidth.  In the MFMA layout a lane holds 4 (8 after the lane swap) consecutive N of ONE row, so a
+// store instruction touches 16 rows x 64 B: sixteen half cache lines.  Here every wave turns its rows around in a private
+// 4 KiB of LDS behind the pipeline stages instead: four 16x16 tiles (16 rows x 64 columns) are written as they sit in the
+// accumulators (ds_write_b64, 16-B chunk c of row r at slot c ^ (r & 7)) and read back row-wise (ds_read_b128: lane ->
+// row lane >> 3 (+ 8), chunk lane & 7), so that one store instruction covers 8 rows x 128 B = eight FULL lines.  Same
+// number of store instructions, half the lines per instruction, no lane swaps.  Two 2 KiB buffers per wave alternate; DS
+// instructions of one wave execute in order, so the only wait is for the read-back data.  The region is wave-private: no
+// barrier, and the next work item's LDS-DMA stream (other regions) keeps flowing underneath.
+#ifndef HGEMM_EPI_STAGED
+#define HGEMM_EPI_STAGED 1
+#endif
+constexpr int SP_STAGED_BYTES_PER_WAVE = 4096;
+template <class CFG>
+constexpr bool sp_staged_ok(int lds_bytes) {
+  return HGEMM_EPI_STAGED && CFG::MI == 16 && CFG::FN % 4 == 0 && lds_bytes + 64 + CFG::NW * SP_STAGED_BYTES_PER_WAVE <= 160 * 1024;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// whole wave tile (FM fragment rows x FN tiles) -> C; `stage` = this wave's 4 KiB.  Accumulators are re-zeroed behind the
+// read when another work item follows.  The stores go through a buffer descriptor that starts at the wave tile's first
+// element and ends with the matrix: rows past M are beyond its range and dropped by the hardware, lanes whose columns lie
+// past N get an out-of-range offset; the position inside the wave tile is a scalar offset (no 64-bit pointer per store).
+// (Reach: the host only takes this path when a 256-row tile spans less than 2 GiB of C, hgemm_api.hip.)
+template <class CFG>
+__device__ __forceinline__ void sp_epilogue_staged(const GemmArgs& g, int m_wave, int n_wave, bool rezero, char* stage) {
+  constexpr int FM = CFG::FM, FN = CFG::FN, NG = FN / 4, GROUPS = FM * NG;
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  using u4 = __attribute__((ext_vector_type(4))) unsigned;
+  // the lane id is re-derived HERE, opaquely: addresses computed from the kernel's own `lane` are loop-invariant, hipcc
+  // hoists all of them to the kernel entry and they stay live across the K loop (+10 VGPRs, SGPR spills in the hot loop)
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
+  const int wrow = lane & 15, wq = lane >> 4;
+  unsigned waddr[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) waddr[jj] = lds0 + wrow * 128 + (((jj * 2 + (wq >> 1)) ^ (wrow & 7)) << 4) + (wq & 1) * 8;
+  const int rrow = lane >> 3, rch = lane & 7;
+  const unsigned raddr = lds0 + rrow * 128 + ((rch ^ (rrow & 7)) << 4);   // rows rrow and rrow + 8 (+1024: same swizzle key)
+  // descriptor: base = &C[m_wave][n_wave] (wave-uniform, made provably so), range = the rest of the matrix
+  const uintptr_t caddr = reinterpret_cast<uintptr_t>(g.C + (size_t)m_wave * g.ldc + n_wave);
+  const uintptr_t cuni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(caddr >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)caddr);
+  const long long rem = ((long long)(g.M - m_wave) * g.ldc - n_wave) * 2;              // bytes from the base to the end of C
+  const unsigned range = __builtin_amdgcn_readfirstlane((int)(rem <= 0 ? 0 : rem > 0x7FFFFFFFLL ? 0x7FFFFFFF : rem));
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)cuni, 0, (int)range, 0x00020000);
+  unsigned voff[NG];
+#pragma unroll
+  for (int gg = 0; gg < NG; ++gg)
+    voff[gg] = (n_wave + gg * 64 + rch * 8 < g.N) ? (unsigned)(rrow * g.ldc + gg * 64 + rch * 8) * 2u : 0x80000000u;
+  const unsigned row8 = (unsigned)g.ldc * 16u;                                          // 8 rows further, in bytes
+  u4 rb[2][2];   // read-back data of the group in flight [buffer][row half]
+  auto write_group = [&](int k) {      // accumulators of group k -> buffer k & 1
+    const int i = k / NG, gg = k % NG;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int x = i * FN + gg * 4 + jj;
+      const f32x4 v = sp_read_acc(x);
+      if (rezero) sp_zero_acc(x);
+      const h2 lo = {(f16)v[0], (f16)v[1]}, hi = {(f16)v[2], (f16)v[3]};
+      const unsigned long long pk = (unsigned long long)__builtin_bit_cast(unsigned, lo) | ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32);
+      if (k & 1) asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(waddr[jj]), "v"(pk) : "memory");
+      else       asm volatile("ds_write_b64 %0, %1" ::"v"(waddr[jj]), "v"(pk) : "memory");
+    }
+  };
+  auto read_group = [&](int k) {
+    if (k & 1) {
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(rb[1][0]) : "v"(raddr) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(rb[1][1]) : "v"(raddr) : "memory");
+    } else {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(rb[0][0]) : "v"(raddr) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rb[0][1]) : "v"(raddr) : "memory");
+    }
+  };
+  auto store_group = [&](int k, bool writes_behind) {
+    const int i = k / NG, gg = k % NG, b = k & 1;
+    // the two reads are older than the (up to four) writes of the next group: in-order return
+    if (writes_behind) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(rb[b][0]), "+v"(rb[b][1])::"memory");
+    else               asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[b][0]), "+v"(rb[b][1])::"memory");
+    if (HGEMM_DBG(g, 2)) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      __builtin_amdgcn_raw_buffer_store_b128(rb[b][h], rsC, voff[gg], (unsigned)(i * 2 + h) * row8, HGEMM_NT_STORE ? 2 : 0);
+  };
+  write_group(0);
+#pragma unroll
+  for (int k = 0; k < GROUPS; ++k) {
+    read_group(k);
+    if (k + 1 < GROUPS) write_group(k + 1);
+    store_group(k, k + 1 < GROUPS);
+  }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
 // EPI: 0 = narrow fp16 epilogue, 1 = wide fp16 epilogue (host checked N % 8, ldc % 8, 16-B aligned C),
 //      2 = fp32 split-K partials for the two-pass combine / the hybrid tail, 3 = single-launch (fused) split-K
 constexpr int SP_EPI_NARROW = 0, SP_EPI_WIDE = 1, SP_EPI_SLAB = 2, SP_EPI_FUSED = 3;
@@ -326,7 +422,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
 
   // the two stages + one word for the fused split-K vote (ONE LDS object: a second one makes hipcc drain
   // vmcnt in front of every ds_read of the pipeline)
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
+  constexpr bool STAGED = EPI == SP_EPI_WIDE && sp_staged_ok<CFG>(CFG::LDS_BYTES);   // + 4 KiB per wave for the epilogue
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64 + (STAGED ? CFG::NW * SP_STAGED_BYTES_PER_WAVE : 0)];
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -403,7 +500,10 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArg
     const int m_wave = tc.m0 + wave_m * CFG::TM, n_wave = tc.n0 + wave_n * CFG::TN;
     const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
     (void)m_wave; (void)n_wave; (void)rsP;
-    if constexpr (MI == 16) {
+    if constexpr (STAGED) {
+      __builtin_amdgcn_sched_barrier(0);
+      sp_epilogue_staged<CFG>(g, m_wave, n_wave, rezero, smem + CFG::LDS_BYTES + 64 + wave * SP_STAGED_BYTES_PER_WAVE);
+    } else if constexpr (MI == 16) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         __builtin_amdgcn_sched_barrier(0);

@@ -51,6 +51,16 @@
 #ifndef HGEMM_SQ_QORDER
 #define HGEMM_SQ_QORDER 0     // behind Q: 0 = B-fragment reads lead the A pieces, 1 = the pieces lead
 #endif
+#ifndef HGEMM_SQ_SPREAD
+#define HGEMM_SQ_SPREAD 1     // 1: the LDS-DMA pieces of a half-tile are spread over a whole interval's worth of slots: the
+                              // first D of them go out behind the sync point that frees their region (as before), the last
+                              // E = NJ - D in the pre-sync window of the NEXT interval, between its leading fragment reads.
+                              // 0: round-2 plan (all pieces in the ~2/3 of an interval behind the sync point, one every 4 slots
+                              // from each of the four waves at once).  Why: round-3 timeline ablation -- the pieces cost 180 of
+                              // the 214 cycles a K-step spends beyond its 2048 MFMA cycles (tools/gpu_round3_a.sh):
+                              // the CU's one address path takes ~20 cycles per piece, four waves x one piece per 64 cycles
+                              // saturates it behind every sync point while it idles in front of the next one.
+#endif
 #ifndef HGEMM_SQ_ABL
 #define HGEMM_SQ_ABL 0        // measurement builds only (results are garbage): drop parts of the K loop to price them with the
                               // timeline stamps: 1 no s_barrier, 2 no vmcnt wait, 4 no lgkmcnt(0) at the sync points,
@@ -90,6 +100,11 @@ struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, MI_, 2> {
   // behind a sync point a DMA piece and a fragment read alternate, one item every ST slots
   static constexpr int STA = (T - P - 1) / (NJB + NFA) >= 2 ? 2 : 1;
   static constexpr int STB = (T - Q - 1) / (NJA + NFB) >= 2 ? 2 : 1;
+  // spread plan: late pieces per operand (issued in the pre-sync window of the following interval: A's in interval A,
+  // in front of P; B's in interval B, in front of Q) in proportion to that window's share of the interval
+  static constexpr int EA = !HGEMM_SQ_SPREAD ? 0 : ((NJA * P + T / 2) / T < NJA ? (NJA * P + T / 2) / T : NJA - 1);
+  static constexpr int EB = !HGEMM_SQ_SPREAD ? 0 : ((NJB * Q + T / 2) / T < NJB ? (NJB * Q + T / 2) / T : NJB - 1);
+  static constexpr int DA = NJA - EA, DB = NJB - EB;       // early pieces (behind the sync point that frees the region)
   static_assert(KT == 1 || KT == 2, "one or two BK=64 sub-tiles per stage");
   static_assert(MI_ == 16 || (MI_ == 32 && KT == 1), "the 32x32x16 members hold K = 64 per stage");
   static_assert(Base::NI % Base::NW == 0 && Base::NI_A % Base::NW == 0, "every wave owns whole A and B pieces");
@@ -127,6 +142,52 @@ struct SqPlan {
     for (int i = 0; i < CFG::NJA; ++i) if (CFG::Q + 1 + CFG::STB * b_item_of_piece(i) == n) return i;
     return -1;
   }
+  // ---- spread plan (HGEMM_SQ_SPREAD): PH = 0 interval A (sync slot P), 1 interval B (sync slot Q) -------------------
+  // late piece k of E, in front of sync slot S: centred in its 1/E share of [0, S), on an odd slot when the leading reads
+  // sit on the even ones
+  static constexpr int late_slot(int k, int E, int S) {
+    int x = ((2 * k + 1) * S) / (2 * E);
+    if (CFG::RS == 2) x |= 1;
+    return x < S ? x : S - 1;
+  }
+  // trailing read i of N behind sync slot S: every second slot when they fit, else every slot
+  static constexpr int trail_step(int N, int S) { return S + 1 + 2 * (N - 1) < T ? 2 : 1; }
+  static constexpr int trail_slot(int i, int N, int S) { return S + 1 + trail_step(N, S) * i; }
+  // early piece k of D behind sync slot S: centred in its 1/D share of (S, T), off the trailing reads' slots
+  static constexpr int early_slot(int k, int D, int S) {
+    int x = S + 1 + ((2 * k + 1) * (T - S - 1)) / (2 * D);
+    if (((x - S) & 1) != 0) ++x;
+    return x < T ? x : T - 1;
+  }
+  template <int PH> static constexpr int sync_slot() { return PH == 0 ? CFG::P : CFG::Q; }
+  template <int PH> static constexpr int n_late() { return PH == 0 ? CFG::EA : CFG::EB; }
+  template <int PH> static constexpr int n_early() { return PH == 0 ? CFG::DB : CFG::DA; }
+  template <int PH> static constexpr int n_trail() { return PH == 0 ? FM : FN; }
+  template <int PH> static constexpr int late_at(int n) {     // late piece (index inside the late group) at slot n, or -1
+    for (int k = 0; k < n_late<PH>(); ++k) if (late_slot(k, n_late<PH>(), sync_slot<PH>()) == n) return k;
+    return -1;
+  }
+  template <int PH> static constexpr int early_at(int n) {
+    for (int k = 0; k < n_early<PH>(); ++k) if (early_slot(k, n_early<PH>(), sync_slot<PH>()) == n) return k;
+    return -1;
+  }
+  template <int PH> static constexpr int trail_at(int n) {
+    for (int i = 0; i < n_trail<PH>(); ++i) if (trail_slot(i, n_trail<PH>(), sync_slot<PH>()) == n) return i;
+    return -1;
+  }
+  template <int PH> static constexpr bool slots_ok() {        // every item has its own slot inside the interval
+    const int S = sync_slot<PH>();
+    for (int k = 0; k < n_late<PH>(); ++k) {
+      if (late_slot(k, n_late<PH>(), S) >= S) return false;
+      if (k && late_slot(k, n_late<PH>(), S) <= late_slot(k - 1, n_late<PH>(), S)) return false;
+    }
+    for (int k = 0; k < n_early<PH>(); ++k) {
+      if (early_slot(k, n_early<PH>(), S) >= T || early_slot(k, n_early<PH>(), S) <= S) return false;
+      if (k && early_slot(k, n_early<PH>(), S) <= early_slot(k - 1, n_early<PH>(), S)) return false;
+    }
+    return trail_slot(n_trail<PH>() - 1, n_trail<PH>(), S) < T;
+  }
+  static_assert(!HGEMM_SQ_SPREAD || (slots_ok<0>() && slots_ok<1>()), "spread slot plan does not fit the interval");
 };
 
 // LDS-DMA piece `idx` (0 .. KT*P_op - 1) of operand OP for the stage at `stage`: sub-tile idx / P_op, 8-row
@@ -146,16 +207,22 @@ __device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, const 
 // behind P: B pieces of tile t+2 and trailing reads -> trail (A fragments of the second half of tile t+1).
 // PHASE 1 = B(t): leading reads -> lead (A fragments of the first half of tile t+1); behind Q: trailing reads ->
 // trail (B fragments of the first half of tile t+1) and A pieces of tile t+3.
+// Spread plan: the pieces behind the sync point are the FIRST D of the half-tile ("early", descriptor / cursor rs_e,
+// kbyte_e, stage_e); in front of it go the LAST E pieces of the half-tile whose region the previous sync point freed
+// ("late": interval A: A pieces of tile t+2 into A[s]; interval B: B pieces of tile t+2 into B[s]; rs_l, kbyte_l, stage_l).
 // Fragment read r of a set: slice r / F reads from src0 / src1, row block r % F.
 template <class CFG, int PHASE>
 __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f16x8 (&bf)[CFG::NFB],
                                             f16x8 (&lead)[PHASE == 0 ? CFG::NFB : CFG::NFA], const char* lead0, const char* lead1,
                                             f16x8 (&trail)[PHASE == 0 ? CFG::NFA : CFG::NFB], const char* trail0, const char* trail1,
-                                            __amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[CFG::NJ], int wave,
-                                            char* dma_stage, uint32_t kbyte) {
+                                            const uint32_t (&voff)[CFG::NJ], int wave,
+                                            __amdgpu_buffer_rsrc_t rs_l, char* stage_l, uint32_t kbyte_l,
+                                            __amdgpu_buffer_rsrc_t rs_e, char* stage_e, uint32_t kbyte_e) {
   using PL = SqPlan<CFG>;
   constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T, RS = CFG::RS;
   constexpr int NLEAD = PHASE == 0 ? CFG::NFB : CFG::NFA, FLEAD = PHASE == 0 ? FN : FM, FTRAIL = PHASE == 0 ? FM : FN;
+  constexpr int OP_E = PHASE == 0 ? 1 : 0, OP_L = PHASE == 0 ? 0 : 1;          // operand of the early / late pieces
+  constexpr int D_L = PHASE == 0 ? CFG::DA : CFG::DB;                          // late pieces are D_L .. NJ_op - 1 of their half-tile
 #pragma unroll
   for (int n = 0; n < T; ++n) {
     const int u = n / (FM * FN), i = (n / FN) % FM, j = n % FN;   // MFMA k-slice, accumulator tile (i, j)
@@ -172,14 +239,21 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       const int r = n / RS;
       lead[r] = *(const f16x8*)((r / FLEAD ? lead1 : lead0) + (r % FLEAD) * CFG::MI * ROW_BYTES);
     }
-    if (PHASE == 0) {
+    if constexpr (HGEMM_SQ_SPREAD) {
+      const int l = (HGEMM_SQ_ABL & 8) ? -1 : PL::template late_at<PHASE>(n);
+      const int e = (HGEMM_SQ_ABL & 8) ? -1 : PL::template early_at<PHASE>(n);
+      const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::template trail_at<PHASE>(n);
+      if (l >= 0) sq_issue_piece<CFG, OP_L>(rs_l, voff, stage_l, wave, D_L + l, kbyte_l);
+      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
+      if (e >= 0) sq_issue_piece<CFG, OP_E>(rs_e, voff, stage_e, wave, e, kbyte_e);
+    } else if (PHASE == 0) {
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::a_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::a_piece_at(n);
-      if (p >= 0) sq_issue_piece<CFG, 1>(rs, voff, dma_stage, wave, p, kbyte);
+      if (p >= 0) sq_issue_piece<CFG, 1>(rs_e, voff, stage_e, wave, p, kbyte_e);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
     } else {
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::b_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::b_piece_at(n);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
-      if (p >= 0) sq_issue_piece<CFG, 0>(rs, voff, dma_stage, wave, p, kbyte);
+      if (p >= 0) sq_issue_piece<CFG, 0>(rs_e, voff, stage_e, wave, p, kbyte_e);
     }
   }
 }
@@ -247,14 +321,21 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
 // (MI = 32: its k = 16 slice u); KT = 2: sub-tile image h, K = 32 half u.
 #define SQ_FRAG(STAGE, OPOFF, H, U) ((STAGE) + (CFG::KT == 2 ? (H) * CFG::SUB_BYTES : 0) + (OPOFF) + \
                                      foff[CFG::KT == 2 ? (U) : (H)][CFG::KT == 2 ? 0 : (U) % CFG::KS])
-#define SQ_K_STEP(YS, ZS)                                                                                       \
+// ADV0 / ADV1 move the A / B stream one stage on.  The A stream moves between the two intervals: interval A still issues
+// the late pieces of the A tile the cursor points at, interval B the early pieces of the next one.  The B stream moves
+// behind interval B (early pieces in interval A, late ones in interval B, same tile).
+#define SQ_K_STEP(YS, ZS, ADV0, ADV1)                                                                           \
   do {                                                                                                          \
     char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                           \
     char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                     \
     sq_interval<CFG, 0>(fX, fU, fV, SQ_FRAG(st, b_base_off, 1, 0), SQ_FRAG(st, b_base_off, 1, 1),               \
-                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), rsB, voff, wave, st, cur[1].kbyte); \
+                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), voff, wave,         \
+                        rsA, st, cur[0].kbyte, rsB, st, cur[1].kbyte);                                          \
+    ADV0;                                                                                                       \
     sq_interval<CFG, 1>(YS, fV, fX, SQ_FRAG(nst, a_base_off, 0, 0), SQ_FRAG(nst, a_base_off, 0, 1),             \
-                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), rsA, voff, wave, nst, cur[0].kbyte); \
+                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), voff, wave,         \
+                        rsB, st, cur[1].kbyte, rsA, nst, cur[0].kbyte);                                         \
+    ADV1;                                                                                                       \
     ++step;                                                                                                     \
   } while (0)
 
@@ -267,7 +348,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   constexpr int NQ = CFG::ACC / 4;              // f32x4 quads per accumulator tile
 
   // the two stages + one word for the single-launch split-K vote (ONE LDS object, see hgemm_kernel_sp.hpp)
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
+  constexpr bool STAGED = EPI == SP_EPI_WIDE && sp_staged_ok<CFG>(CFG::LDS_BYTES);   // + 4 KiB per wave for the epilogue
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64 + (STAGED ? CFG::NW * SP_STAGED_BYTES_PER_WAVE : 0)];
 
   const int tid  = threadIdx.x;
   // (measurement build: stamps go to the 64 scratch bytes behind the stages; slot 0 doubles as the fused vote word,
@@ -327,12 +409,12 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   }
 #pragma unroll
   for (int r = 0; r < NFB; ++r) fU[r] = *(const f16x8*)(SQ_FRAG(smem, b_base_off, 0, r / FN) + (r % FN) * MI * ROW_BYTES);
-  // the A region of stage 0 is consumed: A(2) goes there (sync = the "Q" of a virtual K-step -1)
+  // the A region of stage 0 is consumed: the early pieces of A(2) go there (sync = the "Q" of a virtual K-step -1); its late
+  // pieces follow in interval A of the first K-step, which then moves the A stream on
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   sp_sync();
 #pragma unroll
-  for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voff, smem, wave, p, cur[0].kbyte);
-  SQ_ADVANCE(0);
+  for (int p = 0; p < CFG::DA; ++p) sq_issue_piece<CFG, 0>(rsA, voff, smem, wave, p, cur[0].kbyte);
 
   int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
   HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 2, tid);
@@ -341,28 +423,23 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
     const TileCoord tc = map_logical(g, walk.base + walk.first + item * walk.stride, BM, BN);
     const int nk = __builtin_amdgcn_readfirstlane(tc.nk / CFG::KT);
     HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 3, tid);
-    // hot loop, two K-steps per trip: both streams stay inside this work item (the A stream issues tile t+3
-    // in K-step t and is then moved on: the trip's last move must stay inside the item, t + 5 < nk), so moving
-    // them on is a scalar add
+    // hot loop, two K-steps per trip: both streams stay inside this work item (in K-step t the A stream moves on to tile
+    // t+3 and the B stream to tile t+3 behind it: the trip's last move, to t+4, must stay inside the item; t + 5 < nk keeps
+    // one more step of margin, as the round-2 plan needed), so moving them on is a scalar add
     int t = 0;
 #pragma clang loop unroll(disable)
     for (; t + 5 < nk; t += 2) {
-      SQ_K_STEP(fY, fZ);
-      SQ_STEP_CURSOR(0); SQ_STEP_CURSOR(1);
-      SQ_K_STEP(fZ, fY);
-      SQ_STEP_CURSOR(0); SQ_STEP_CURSOR(1);
+      SQ_K_STEP(fY, fZ, SQ_STEP_CURSOR(0), SQ_STEP_CURSOR(1));
+      SQ_K_STEP(fZ, fY, SQ_STEP_CURSOR(0), SQ_STEP_CURSOR(1));
     }
     // last (up to) six K-steps: the streams may cross into the next work item
 #pragma clang loop unroll(disable)
     for (; t + 1 < nk; t += 2) {
-      SQ_K_STEP(fY, fZ);
-      SQ_ADVANCE(0); SQ_ADVANCE(1);
-      SQ_K_STEP(fZ, fY);
-      SQ_ADVANCE(0); SQ_ADVANCE(1);
+      SQ_K_STEP(fY, fZ, SQ_ADVANCE(0), SQ_ADVANCE(1));
+      SQ_K_STEP(fZ, fY, SQ_ADVANCE(0), SQ_ADVANCE(1));
     }
     if (t < nk) {   // odd K-step count: one more step, then put the next tile's slice-1 fragments back into Y
-      SQ_K_STEP(fY, fZ);
-      SQ_ADVANCE(0); SQ_ADVANCE(1);
+      SQ_K_STEP(fY, fZ, SQ_ADVANCE(0), SQ_ADVANCE(1));
 #pragma unroll
       for (int r = 0; r < NFA; ++r) fY[r] = fZ[r];
     }
@@ -373,7 +450,10 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
     const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
     const int m_wave = tc.m0 + wave_m * CFG::TM, n_wave = tc.n0 + wave_n * CFG::TN;
     (void)rsP; (void)m_wave; (void)n_wave;
-    if constexpr (MI == 16) {
+    if constexpr (STAGED) {
+      __builtin_amdgcn_sched_barrier(0);
+      sp_epilogue_staged<CFG>(g, m_wave, n_wave, rezero, smem + CFG::LDS_BYTES + 64 + wave * SP_STAGED_BYTES_PER_WAVE);
+    } else if constexpr (MI == 16) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         __builtin_amdgcn_sched_barrier(0);

@@ -9,6 +9,8 @@ never spans GPUs, so multi-GPU = independent shards, no collective (SURVEY.md se
 
   python tools/sweep.py run   --out results --acc_precise fp32 --mode offline [--gpus 8] [--shapes-file f]
   python tools/sweep.py run   --inprocess ...   same metric without the per-baseline process churn (tools/sweep_inprocess.py)
+  python tools/sweep.py run   --device cpu ...  plumbing run without a GPU (BASELINE config 1): every shape of the shard goes
+                                                through benchmarking_offline.py --device cpu --perf_func matmul
   python tools/sweep.py merge --out results --acc_precise fp32 --mode offline
 Launched under torch.distributed.run it takes rank/world size from RANK / WORLD_SIZE / LOCAL_RANK.
 
@@ -57,6 +59,35 @@ def shape_dir(out: Path, acc: str, mode: str, mnk: str) -> Path:
 
 def is_done(out: Path, acc: str, mode: str, mnk: str) -> bool:
     return (shape_dir(out, acc, mode, mnk) / "summary.json").exists()
+
+
+def status_path(out: Path, acc: str, mode: str, rank: int) -> Path:
+    """One status file per (accumulate tree, mode, rank), next to that sweep's records: `merge` reads them from there."""
+    return out / f"{acc}_{mode}" / f"rank{rank}_status.json"
+
+
+def run_shapes_cpu(shapes, args, rank: int) -> dict:
+    """BASELINE config 1 for a whole shard: the harness's own CPU plumbing path (benchmarking_offline.py --device cpu
+    --perf_func matmul, one process per shape as the reference's flow), no extension, no GPU."""
+    done = skipped = failed = 0
+    t0 = time.time()
+    for mnk in shapes:
+        d = shape_dir(args.out, args.acc_precise, args.mode, mnk)
+        if (d / "benchmark_result_matmul.json").exists():
+            skipped += 1
+            continue
+        cmd = [sys.executable, str(PKG_DIR / "benchmarking_offline.py"), "--mnk", mnk, "--acc_precise", args.acc_precise,
+               "--device_type", "mi355x", "--base_dir", str(d), "--gpu_device_id", "0", "--device", "cpu", "--perf_func", "matmul",
+               "--warmup_seconds", str(args.warmup_seconds), "--benchmark_seconds", str(args.benchmark_seconds)]
+        res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(PKG_DIR))
+        d.mkdir(parents=True, exist_ok=True)
+        (d / "eval.log").write_text(res.stdout + res.stderr)
+        if res.returncode == 0:
+            done += 1
+        else:
+            failed += 1
+            print(f"[rank {rank}] {mnk} FAILED (see {d / 'eval.log'})", flush=True)
+    return {"rank": rank, "gpu": None, "device": "cpu", "done": done, "skipped": skipped, "failed": failed, "seconds": time.time() - t0}
 
 
 def run_shapes(shapes, args, rank: int, gpu: int) -> dict:
@@ -128,6 +159,21 @@ def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
             ours = lat.get(f"cuda_l2_mi355x_{acc}", {})
             base = lat.get("hipBLASLt-auto-tuning-tn", lat.get("hipBLASLt-heuristic-tn", {}))
             lat_rows.append([mnk, ours.get("p50"), ours.get("p99"), base.get("p50"), base.get("p99")])
+    # CPU plumbing records (run --device cpu): torch.matmul on the host, the harness's own numbers
+    plumbing = {}
+    for mnk in shapes:
+        f = shape_dir(out, acc, mode, mnk) / "benchmark_result_matmul.json"
+        if f.exists():
+            r = json.loads(f.read_text())
+            if r.get("device") == "cpu":
+                plumbing[mnk] = r
+    if plumbing and not cpu_time:
+        for mnk, r in plumbing.items():
+            tf = r["records"]["matmul"]
+            cpu_flops += flops(mnk); cpu_time += flops(mnk) / (tf * 1e12); cpu_info = r.get("cpu")
+            tf_rows.append([mnk, None, None, None, tf])
+        if not total_flops:
+            total_flops = cpu_flops
     name = f"cuda_l2_mi355x_{ACC_DIRS[acc]}_speedup_{mode}.csv"
     with open(out / name, "w") as f:
         f.write("mnk," + ",".join(CSV_COLUMNS) + "\n")
@@ -136,13 +182,13 @@ def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
     with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_tflops_{mode}.csv", "w") as f:
         f.write("mnk,cuda_l2_tflops,hipblaslt_autotune_max_tflops,torch_matmul_tflops,cpu_torch_matmul_tflops\n")
         for r in tf_rows:
-            f.write(f"{r[0]},{r[1]:.3f},{r[2]:.3f},{r[3]:.3f},{'' if r[4] is None else format(r[4], '.4f')}\n")
+            f.write(r[0] + "," + ",".join("" if v is None else format(v, ".4f" if i == 3 else ".3f") for i, v in enumerate(r[1:])) + "\n")
     if lat_rows:
         with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_latency_{mode}.csv", "w") as f:
             f.write("mnk,cuda_l2_p50_ms,cuda_l2_p99_ms,hipblaslt_tn_p50_ms,hipblaslt_tn_p99_ms\n")
             for r in lat_rows:
                 f.write(r[0] + "," + ",".join("" if v is None else f"{v:.5f}" for v in r[1:]) + "\n")
-    report = {"shapes": len(rows), "csv": str(out / name)}
+    report = {"shapes": len(rows), "cpu_plumbing_shapes": len(plumbing), "csv": str(out / name)}
     for i, c in enumerate(CSV_COLUMNS):
         col = [r[1 + i] for r in rows]
         report[f"geomean_speedup_vs_{c}"] = geomean(col)
@@ -152,6 +198,7 @@ def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
     for f in sorted((out / f"{acc}_{mode}").glob("rank*_status.json")):
         st = json.loads(f.read_text())
         walls[st["rank"]] = st["seconds"]
+    report["rank_status"] = [json.loads(f.read_text()) for f in sorted((out / f"{acc}_{mode}").glob("rank*_status.json"))]
     rank_walls = {}
     for item in recs.values():
         if item["rec"] is not None:
@@ -183,6 +230,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=None, help="world size when not launched by torch.distributed.run")
     ap.add_argument("--rank", type=int, default=None)
     ap.add_argument("--inprocess", action="store_true", help="run: one process per GPU evaluates its shard (tools/sweep_inprocess.py)")
+    ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda", help="run: cpu = plumbing sweep of torch.matmul on the host cores")
     from tools import sweep_inprocess
 
     sweep_inprocess.add_args(ap)
@@ -209,8 +257,12 @@ def main(argv=None):
         print(json.dumps(status))
         return status
     if args.command == "run":
-        status = run_shapes(shard(shapes, rank, world), args, rank, gpu)
-        (args.out / f"rank{rank}_status.json").write_text(json.dumps(status))
+        mine = shard(shapes, rank, world)
+        status = run_shapes_cpu(mine, args, rank) if args.device == "cpu" else run_shapes(mine, args, rank, gpu)
+        status["world"] = world
+        sp = status_path(args.out, args.acc_precise, args.mode, rank)
+        sp.parent.mkdir(parents=True, exist_ok=True)
+        sp.write_text(json.dumps(status))
         print(json.dumps(status))
         return status
     report = merge(args.out, args.acc_precise, args.mode, shapes)

@@ -134,8 +134,15 @@ int hgemm_mi355x_config_k_granularity(int config_id);
  * captured on that stream (or run the shape once on it); otherwise the captured call runs with splits = 1.
  * A buffer that a capture has used is never freed by later growth (it is retired until
  * hgemm_mi355x_release_workspaces), so instantiated graphs stay valid.  Replays of graphs captured on one
- * stream share that stream's workspace: do not replay them concurrently on several streams. */
+ * stream share that stream's workspace: do not replay them concurrently on several streams.
+ *
+ * Cost and lifetime: a (device, stream) pair that ever ran a split-K / hybrid plan keeps its buffer (>= 8 MiB, grown
+ * geometrically) until hgemm_mi355x_release_workspaces; destroying the stream frees nothing, so an application with many
+ * short-lived streams calls hgemm_mi355x_release_stream_workspace(stream) (current device, nothing of that stream in
+ * flight) before hipStreamDestroy.  Allocation and growth switch the calling thread's stream-capture mode to relaxed
+ * around hipMalloc / hipFree, so a capture that ANOTHER stream runs in global mode is not invalidated by them. */
 int hgemm_mi355x_set_workspace(void* device_ptr, size_t bytes);
+int hgemm_mi355x_release_stream_workspace(void* stream);
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits);
 int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream);
 int hgemm_mi355x_release_workspaces(void);

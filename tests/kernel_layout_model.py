@@ -251,30 +251,64 @@ def sp_plan(FM: int, FN: int, NJA: int, NJB: int, RS: int = 2):
 
 
 # ---- family "q" (hgemm_kernel_sq.hpp): early-A operand split, two sync points per pipeline stage ---------------
-def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, rs64: int = 2, MI: int = 16, slack32: int = 4):
-    """Mirror of CfgSQ / SqPlan: slot numbers of the leading reads, the sync point and the (DMA piece, trailing read)
-    items of interval A (phase 0) and interval B (phase 1).  FM, FN = MFMA tiles per wave tile (TM / MI, TN / MI);
-    MI = 32 runs two k = 16 MFMA slices per K = 32 interval."""
+def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, rs64: int = 2, MI: int = 16, slack32: int = 4,
+            spread: bool = True):
+    """Mirror of CfgSQ / SqPlan: slot numbers of the leading reads, the sync point, the trailing reads and the LDS-DMA
+    pieces of interval A (phase 0) and interval B (phase 1).  FM, FN = MFMA tiles per wave tile (TM / MI, TN / MI);
+    MI = 32 runs two k = 16 MFMA slices per K = 32 interval.
+    spread (round 3, HGEMM_SQ_SPREAD): a half-tile's first D pieces go out behind the sync point that frees its region
+    ("early_*"), its last E pieces in front of the NEXT interval's sync point ("late_*": interval A carries the late
+    pieces of the A half-tile, interval B those of the B half-tile).  spread = False is the round-2 plan (E = 0)."""
     SL = KT * (1 if MI == 16 else 2)
     NFA, NFB, T = FM * SL, FN * SL, FM * FN * SL
     NJA, NJB = KT * PA, KT * PB
     RS = rs64 if T >= 64 else 1
     slack = slack32 if MI == 32 else slack64 if T >= 64 else (6 if T >= 32 else 2)
     P, Q = RS * NFB + slack, RS * NFA + slack
-    STA = 2 if (T - P - 1) // (NJB + NFA) >= 2 else 1
-    STB = 2 if (T - Q - 1) // (NJA + NFB) >= 2 else 1
+    base = {"T": T, "P": P, "Q": Q, "NJA": NJA, "NJB": NJB, "NFA": NFA, "NFB": NFB,
+            "lead_A": [RS * r for r in range(NFB)], "lead_B": [RS * r for r in range(NFA)]}
+    if not spread:
+        STA = 2 if (T - P - 1) // (NJB + NFA) >= 2 else 1
+        STB = 2 if (T - Q - 1) // (NJA + NFB) >= 2 else 1
 
-    def interleave(first_n, second_n):     # item index of element i of the list that goes first / second
-        first = [2 * i if i < second_n else second_n + i for i in range(first_n)]
-        second = [2 * i + 1 if i < first_n else first_n + i for i in range(second_n)]
-        return first, second
+        def interleave(first_n, second_n):     # item index of element i of the list that goes first / second
+            first = [2 * i if i < second_n else second_n + i for i in range(first_n)]
+            second = [2 * i + 1 if i < first_n else first_n + i for i in range(second_n)]
+            return first, second
 
-    a_piece_items, a_read_items = interleave(NJB, NFA)       # behind P: B pieces lead, A-fragment reads follow
-    b_read_items, b_piece_items = interleave(NFB, NJA)       # behind Q: B-fragment reads lead, A pieces follow
-    return {"T": T, "P": P, "Q": Q, "NJA": NJA, "NJB": NJB, "NFA": NFA, "NFB": NFB,
-            "lead_A": [RS * r for r in range(NFB)], "lead_B": [RS * r for r in range(NFA)],
-            "pieces_A": [P + 1 + STA * i for i in a_piece_items], "reads_A": [P + 1 + STA * i for i in a_read_items],
-            "reads_B": [Q + 1 + STB * i for i in b_read_items], "pieces_B": [Q + 1 + STB * i for i in b_piece_items]}
+        a_piece_items, a_read_items = interleave(NJB, NFA)       # behind P: B pieces lead, A-fragment reads follow
+        b_read_items, b_piece_items = interleave(NFB, NJA)       # behind Q: B-fragment reads lead, A pieces follow
+        return dict(base, EA=0, EB=0, late_A=[], late_B=[],
+                    pieces_A=[P + 1 + STA * i for i in a_piece_items], reads_A=[P + 1 + STA * i for i in a_read_items],
+                    reads_B=[Q + 1 + STB * i for i in b_read_items], pieces_B=[Q + 1 + STB * i for i in b_piece_items])
+    EA = min((NJA * P + T // 2) // T, NJA - 1)
+    EB = min((NJB * Q + T // 2) // T, NJB - 1)
+
+    def late(E, S):
+        out = []
+        for k in range(E):
+            x = ((2 * k + 1) * S) // (2 * E)
+            if RS == 2:
+                x |= 1
+            out.append(min(x, S - 1))
+        return out
+
+    def trail(N, S):
+        step = 2 if S + 1 + 2 * (N - 1) < T else 1
+        return [S + 1 + step * i for i in range(N)]
+
+    def early(D, S):
+        out = []
+        for k in range(D):
+            x = S + 1 + ((2 * k + 1) * (T - S - 1)) // (2 * D)
+            if (x - S) & 1:
+                x += 1
+            out.append(min(x, T - 1))
+        return out
+
+    # interval A: late A pieces, sync P, trailing A-fragment reads, early B pieces; interval B: late B, Q, B reads, early A
+    return dict(base, EA=EA, EB=EB, late_A=late(EA, P), late_B=late(EB, Q),
+                reads_A=trail(NFA, P), pieces_A=early(NJB - EB, P), reads_B=trail(NFB, Q), pieces_B=early(NJA - EA, Q))
 
 
 def sq_schedule_hazards(plan: dict, steps: int = 8):
@@ -287,14 +321,15 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
       WAR  a DMA piece into a region must come behind a sync point (lgkmcnt(0) + barrier) that follows every read of
            the region's previous occupant (tile t-2).
     All four waves run the same stream and leave a sync point together, so one stream is enough.  Returns a list of
-    violations (empty = the plan is hazard-free)."""
+    violations (empty = the plan is hazard-free).  Every tile must also receive exactly its NJ pieces."""
     T, NJA, NJB = plan["T"], plan["NJA"], plan["NJB"]
+    EA, EB = plan.get("EA", 0), plan.get("EB", 0)
     events = []   # (time, kind, operand, tile); time = (interval index) * (T + 1) + slot, sync sorts before its slot's MFMA
 
     def at(interval, slot, half=0):
         return interval * 2 * (T + 2) + slot * 2 + half
 
-    # prologue: pieces of tiles 0, 1 (A then B each), sync, reads of tile 0 (A both halves, B first half), sync, A(2)
+    # prologue: pieces of tiles 0, 1 (A then B each), sync, reads of tile 0 (A both halves, B first half), sync, early A(2)
     t0 = -10 * (T + 2)
     order = 0
     for tile in (0, 1):
@@ -305,12 +340,14 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
     for op, half in (("A", 0), ("A", 1), ("B", 0)):
         events.append((t0 + order, "read", op, (0, half))); order += 1
     events.append((t0 + order, "sync_lgkm", None, None)); order += 1
-    for _ in range(NJA):
+    for _ in range(NJA - EA):
         events.append((t0 + order, "dma", "A", 2)); order += 1
     for t in range(steps):
         ia, ib = 2 * t, 2 * t + 1
         for s in plan["lead_A"]:
             events.append((at(ia, s, 1), "read", "B", (t, 1)))
+        for s in plan.get("late_A", []):
+            events.append((at(ia, s, 1), "dma", "A", t + 2))     # the A stream still points at tile t+2 here
         events.append((at(ia, plan["P"], 0), "sync_both", NJA + NJB, None))
         for s in plan["pieces_A"]:
             events.append((at(ia, s, 1), "dma", "B", t + 2))
@@ -318,6 +355,8 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
             events.append((at(ia, s, 1), "read", "A", (t + 1, 1)))
         for s in plan["lead_B"]:
             events.append((at(ib, s, 1), "read", "A", (t + 1, 0)))
+        for s in plan.get("late_B", []):
+            events.append((at(ib, s, 1), "dma", "B", t + 2))
         events.append((at(ib, plan["Q"], 0), "sync_both", NJA + NJB, None))
         for s in plan["reads_B"]:
             events.append((at(ib, s, 1), "read", "B", (t + 1, 0)))
@@ -326,6 +365,11 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
     events.sort(key=lambda e: e[0])
     bad = []
     dmas = [e for e in events if e[1] == "dma"]
+    for op, nj in (("A", NJA), ("B", NJB)):
+        for tile in range(2, steps + 1):
+            got = sum(1 for e in dmas if e[2] == op and e[3] == tile)
+            if got != nj:
+                bad.append(("PIECES", op, tile, got))
     for time, kind, op, what in events:
         if kind == "read":
             tile = what[0]
@@ -409,3 +453,39 @@ def rs_frag_read_addrs(bks: int, ks: int, i: int = 0):
         assert addr == row * rb + ((chunk ^ (row & 15)) << 4)     # = where rs_write_addrs put (row, chunk)
         out.append(addr)
     return out
+
+
+# ---- LDS-staged fp16 epilogue (sp_epilogue_staged in hgemm_kernel_sp.hpp) -----------------------------------------
+def staged_epilogue_roundtrip():
+    """One group (four 16x16 accumulator tiles = 16 rows x 64 columns) through a wave's 2 KiB staging buffer.
+    Returns (out, write_conflicts, read_conflicts): out[(lane, h, e)] = (row, col) of the element lane `lane` holds in
+    half e of the 16 bytes it reads back for row half h; conflicts = extra LDS cycles of the 4 ds_write_b64 / 2 ds_read_b128."""
+    lds = {}
+    wconf = 0
+    for jj in range(4):
+        addrs = []
+        for lane in range(64):
+            wrow, wq = lane & 15, lane >> 4
+            a = wrow * 128 + (((jj * 2 + (wq >> 1)) ^ (wrow & 7)) << 4) + (wq & 1) * 8
+            addrs.append(a)
+            for e in range(4):
+                assert a + 2 * e not in lds, "two lanes write the same staging bytes"
+                lds[a + 2 * e] = (wrow, jj * 16 + wq * 4 + e)       # MFMA layout: row lane & 15, 4 consecutive N per lane
+        for g0 in range(0, 64, 16):                                  # ds_write_b64: contiguous 16-lane groups, 32 banks
+            per_bank = {}
+            for lane in range(g0, g0 + 16):
+                for dw in range(2):
+                    per_bank.setdefault(((addrs[lane] // 4) + dw) % 32, set()).add((addrs[lane] // 4) + dw)
+            wconf += max(len(v) for v in per_bank.values()) - 1
+    out = {}
+    rconf = 0
+    for h in range(2):
+        addrs = []
+        for lane in range(64):
+            rrow, rch = lane >> 3, lane & 7
+            a = rrow * 128 + ((rch ^ (rrow & 7)) << 4) + h * 1024
+            addrs.append(a)
+            for e in range(8):
+                out[(lane, h, e)] = lds[a + 2 * e]
+        rconf += bank_conflict_extra_cycles(addrs)
+    return out, wconf, rconf

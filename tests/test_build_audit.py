@@ -69,8 +69,16 @@ def test_sp_kernels_do_not_spill_and_leave_room_for_the_agprs(sp_functions):
         accum = re.search(r"\.amdhsa_accum_offset (\d+)", meta[name])
         assert m and accum
         assert int(m.group(1)) - int(accum.group(1)) == 256, f"{name}: expected 256 AGPRs"
-        assert int(accum.group(1)) <= 256, f"{name}: {accum.group(1)} VGPRs: the allocator would have to spill into the reserved AGPRs"
         assert int(m.group(1)) <= 512
+        # VGPR headroom below the reserved AGPRs, per epilogue class (the last template argument): the plain epilogues
+        # (narrow 0 / wide 1) are what the compute-bound plans run and keep >= 32 registers of margin, the slab epilogue
+        # (2) >= 16; only the single-launch split-K form (3: fragments + a combine row live together) may use the file
+        # up to the last register -- a compiler bump that costs one more there fails the 256-AGPR check above instead of
+        # silently spilling.  The table is printed (pytest -s / on failure) so a creeping allocation is visible early.
+        epi = int(re.search(r"ELi(\d)EEEvNS", name).group(1))
+        bound = {0: 224, 1: 224, 2: 240, 3: 256}[epi]
+        print(f"accum_offset {accum.group(1):>3} (bound {bound})  {name}")
+        assert int(accum.group(1)) <= bound, f"{name}: {accum.group(1)} VGPRs > {bound} (epilogue class {epi})"
 
 
 def test_sp_k_loops_are_mfma_streams_with_scalar_dma_descriptors(sp_functions):

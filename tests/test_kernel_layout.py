@@ -175,16 +175,21 @@ def test_family_q_schedule_has_no_lds_hazard(bm, bn, wm, wn, kt, mi):
     nw = wm * wn
     FM, FN = bm // wm // mi, bn // wn // mi
     PA, PB = bm // 8 // nw, bn // 8 // nw
-    for slack, rs in [(6, 2), (2, 2), (12, 2), (6, 1)]:
-        plan = klm.sq_plan(FM, FN, PA, PB, kt, slack, rs, mi, slack32=min(slack, 6))
-        T = plan["T"]
-        slots = plan["pieces_A"] + plan["reads_A"]
-        assert len(set(slots)) == len(slots) and max(slots) < T and min(slots) > plan["P"]
-        slots = plan["pieces_B"] + plan["reads_B"]
-        assert len(set(slots)) == len(slots) and max(slots) < T and min(slots) > plan["Q"]
-        assert max(plan["lead_A"]) < plan["P"] and max(plan["lead_B"]) < plan["Q"]
-        assert plan["NJA"] + plan["NJB"] <= 63                      # vmcnt is a 6-bit counter
-        assert klm.sq_schedule_hazards(plan) == []
+    for spread in (True, False):
+        for slack, rs in [(6, 2), (2, 2), (12, 2), (6, 1)]:
+            plan = klm.sq_plan(FM, FN, PA, PB, kt, slack, rs, mi, slack32=min(slack, 6), spread=spread)
+            T = plan["T"]
+            for pieces, reads, late, sync in ((plan["pieces_A"], plan["reads_A"], plan["late_A"], plan["P"]),
+                                              (plan["pieces_B"], plan["reads_B"], plan["late_B"], plan["Q"])):
+                assert len(set(pieces)) == len(pieces) and len(set(reads)) == len(reads) and len(set(late)) == len(late)
+                assert max(pieces + reads) < T and min(pieces + reads) > sync
+                assert all(0 <= x < sync for x in late)
+                if not spread:
+                    assert len(set(pieces + reads)) == len(pieces + reads) and not late
+            assert len(plan["late_A"]) + len(plan["pieces_B"]) == plan["NJA"] and len(plan["late_B"]) + len(plan["pieces_A"]) == plan["NJB"]
+            assert max(plan["lead_A"]) < plan["P"] and max(plan["lead_B"]) < plan["Q"]
+            assert plan["NJA"] + plan["NJB"] <= 63                      # vmcnt is a 6-bit counter
+            assert klm.sq_schedule_hazards(plan) == []
 
 
 def test_family_q_hazard_model_catches_a_misplaced_wait():
@@ -195,6 +200,13 @@ def test_family_q_hazard_model_catches_a_misplaced_wait():
     assert any(v[0] == "RAW" for v in klm.sq_schedule_hazards(early_read))
     early_dma = dict(plan, pieces_B=[plan["Q"] - 1 - i for i in range(len(plan["pieces_B"]))])
     assert any(v[0] == "WAR" for v in klm.sq_schedule_hazards(early_dma))
+    # the spread plan's own risks: a half-tile that loses a late piece, and a late piece that lands in front of the reads of
+    # the region's previous occupant (interval B's late B pieces moved into interval A, ahead of the slice-1 B reads)
+    assert plan["late_A"] and plan["late_B"]
+    lost = dict(plan, late_A=plan["late_A"][:-1])
+    assert any(v[0] == "PIECES" for v in klm.sq_schedule_hazards(lost))
+    wrong_window = dict(plan, late_B=[], pieces_A=plan["pieces_A"] + [0] * len(plan["late_B"]))
+    assert any(v[0] in ("WAR", "RAW") for v in klm.sq_schedule_hazards(wrong_window))
 
 
 def test_fused_split_k_slab_layout_is_a_bijection():
@@ -237,3 +249,17 @@ def test_family_r_lds_image_is_consistent_and_conflict_free(bks):
             assert klm.bank_conflict_extra_cycles(reads) == 0
             for lane, a in enumerate(reads):
                 assert seen[(i * 16 + (lane & 15), 4 * ks + (lane >> 4))] == a
+
+
+def test_staged_epilogue_turns_mfma_tiles_into_full_rows():
+    """sp_epilogue_staged: after the round trip through the wave's LDS buffer lane l holds, for row half h, the eight
+    consecutive columns 8 * (l & 7) .. + 7 of row (l >> 3) + 8h -- i.e. one store instruction writes 8 rows x 128 B; every
+    staged element is read back exactly once; the row-wise reads are conflict-free, the tile-wise writes at most 2-way."""
+    out, wconf, rconf = klm.staged_epilogue_roundtrip()
+    seen = set()
+    for (lane, h, e), (row, col) in out.items():
+        assert row == (lane >> 3) + 8 * h and col == (lane & 7) * 8 + e
+        seen.add((row, col))
+    assert len(seen) == 16 * 64 == len(out)
+    assert rconf == 0
+    assert wconf <= 4 * 4          # four ds_write_b64, four lane groups each, one extra cycle (rows r and r + 8) at most

@@ -53,3 +53,40 @@ def test_two_rank_sharding_and_reduction():
     assert sorted(gathered[0] + gathered[1]) == sorted(f"{64 * (i + 1)}_128_64" for i in range(7))
     assert abs(elapsed - 0.020) < 1e-9      # max over ranks
     assert flops == total                    # whole-job work = sum over ranks
+
+
+def test_two_rank_cpu_sweep_run_then_merge(tmp_path):
+    """tools/sweep.py end to end on two ranks without a GPU (BASELINE config 1, the harness's --device cpu plumbing path):
+    launched the way the driver launches a multi-GPU job (torch.distributed.run, 127.0.0.1 rendezvous), every rank
+    evaluates shapes[rank::2] through benchmarking_offline.py, the results meet on the filesystem and `merge` reads BOTH
+    rank status files: ranks == 2, max-over-ranks wall, sum 2MNK / that wall and the CPU column are all there."""
+    import json
+    import subprocess
+
+    shapes = ["64_4096_64", "64_128_64", "128_128_64", "64_64_128", "128_64_64", "64_64_64"]
+    out = tmp_path / "sweep"
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    common = ["--out", str(out), "--acc_precise", "fp32", "--mode", "offline", "--shapes", ",".join(shapes)]
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), str(REPO / "cuda-l2_amd" / "tools" / "sweep.py"), "run", "--device", "cpu",
+                          "--warmup_seconds", "0.02", "--benchmark_seconds", "0.05", *common],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    status = sorted((out / "fp32_offline").glob("rank*_status.json"))
+    assert [p.name for p in status] == ["rank0_status.json", "rank1_status.json"]
+    st = [json.loads(p.read_text()) for p in status]
+    assert [s["done"] for s in st] == [3, 3] and all(s["failed"] == 0 and s["world"] == 2 for s in st)
+    merged = subprocess.run([sys.executable, str(REPO / "cuda-l2_amd" / "tools" / "sweep.py"), "merge", *common],
+                            capture_output=True, text=True, env=env, timeout=300)
+    assert merged.returncode == 0, merged.stdout + merged.stderr
+    rep = json.loads(merged.stdout)
+    agg = rep["aggregate"]
+    total = sum(2.0 * m * n * k for m, n, k in (map(int, s.split("_")) for s in shapes))
+    assert rep["cpu_plumbing_shapes"] == 6 and agg["ranks"] == 2
+    assert agg["max_rank_wall_s"] == max(s["seconds"] for s in st) > 0
+    assert agg["total_flops_one_pass"] == total
+    assert abs(agg["sweep_tflops_sum2mnk_over_max_rank_wall"] - total / agg["max_rank_wall_s"] * 1e-12) < 1e-12
+    cpu = agg["cpu_torch_matmul"]
+    assert cpu["shapes"] == 6 and cpu["flop_weighted_tflops"] > 0 and cpu["os_cpu_count"] >= 1
+    # a second sweep (other accumulate tree) keeps its own status files: nothing is overwritten
+    assert not (out / "rank0_status.json").exists()
