@@ -192,15 +192,20 @@ struct SqPlan {
 
 // LDS-DMA piece `idx` (0 .. KT*P_op - 1) of operand OP for the stage at `stage`: sub-tile idx / P_op, 8-row
 // block idx % P_op of this wave; the source advances 128 B per sub-tile.
+// Addressing (round 3): ONE per-lane offset per operand (lane's row of the wave's first 8-row block, swizzled chunk)
+// for the whole kernel; the row block of a piece (wave + p * NW) is the scalar offset p * step, step = NW * 8 rows *
+// ld * 2 B; the descriptor starts at the tile's first row and ENDS WITH THE MATRIX, so rows past the M / N edge are out
+// of range and arrive as zeros.  Round 2 kept one clamped per-lane offset per piece (16 VGPRs, recomputed at every work
+// item with ~160 VALU operations, and held twice by the register allocator around the item seams).
 template <class CFG, int OP>
-__device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[CFG::NJ], char* stage,
+__device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t step, char* stage,
                                                int wave, int idx, uint32_t kbyte) {
   constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
-  const int sub = idx / POP, p = (OP == 0 ? 0 : CFG::PA) + idx % POP;
+  const int sub = idx / POP, q = idx % POP, p = (OP == 0 ? 0 : CFG::PA) + q;
   lds_void_t* dst = (lds_void_t*)(stage + sub * CFG::SUB_BYTES + (wave + p * CFG::NW) * 1024);
   // (the sub-tile's 128 B go into the scalar offset: the instruction's immediate offset would also be added to
   // the LDS address of an LDS-DMA)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff[p], kbyte + sub * ROW_BYTES, 0, HGEMM_DMA_AUX);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, kbyte + sub * ROW_BYTES + (uint32_t)q * step, 0, HGEMM_DMA_AUX);
 }
 
 // One interval.  PHASE 0 = A(t): MFMAs af x bf; leading reads -> lead (B fragments of the second half of tile t);
@@ -215,9 +220,9 @@ template <class CFG, int PHASE>
 __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f16x8 (&bf)[CFG::NFB],
                                             f16x8 (&lead)[PHASE == 0 ? CFG::NFB : CFG::NFA], const char* lead0, const char* lead1,
                                             f16x8 (&trail)[PHASE == 0 ? CFG::NFA : CFG::NFB], const char* trail0, const char* trail1,
-                                            const uint32_t (&voff)[CFG::NJ], int wave,
-                                            __amdgpu_buffer_rsrc_t rs_l, char* stage_l, uint32_t kbyte_l,
-                                            __amdgpu_buffer_rsrc_t rs_e, char* stage_e, uint32_t kbyte_e) {
+                                            int wave,
+                                            __amdgpu_buffer_rsrc_t rs_l, uint32_t voff_l, uint32_t step_l, char* stage_l, uint32_t kbyte_l,
+                                            __amdgpu_buffer_rsrc_t rs_e, uint32_t voff_e, uint32_t step_e, char* stage_e, uint32_t kbyte_e) {
   using PL = SqPlan<CFG>;
   constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T, RS = CFG::RS;
   constexpr int NLEAD = PHASE == 0 ? CFG::NFB : CFG::NFA, FLEAD = PHASE == 0 ? FN : FM, FTRAIL = PHASE == 0 ? FM : FN;
@@ -243,26 +248,25 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       const int l = (HGEMM_SQ_ABL & 8) ? -1 : PL::template late_at<PHASE>(n);
       const int e = (HGEMM_SQ_ABL & 8) ? -1 : PL::template early_at<PHASE>(n);
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::template trail_at<PHASE>(n);
-      if (l >= 0) sq_issue_piece<CFG, OP_L>(rs_l, voff, stage_l, wave, D_L + l, kbyte_l);
+      if (l >= 0) sq_issue_piece<CFG, OP_L>(rs_l, voff_l, step_l, stage_l, wave, D_L + l, kbyte_l);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
-      if (e >= 0) sq_issue_piece<CFG, OP_E>(rs_e, voff, stage_e, wave, e, kbyte_e);
+      if (e >= 0) sq_issue_piece<CFG, OP_E>(rs_e, voff_e, step_e, stage_e, wave, e, kbyte_e);
     } else if (PHASE == 0) {
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::a_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::a_piece_at(n);
-      if (p >= 0) sq_issue_piece<CFG, 1>(rs_e, voff, stage_e, wave, p, kbyte_e);
+      if (p >= 0) sq_issue_piece<CFG, 1>(rs_e, voff_e, step_e, stage_e, wave, p, kbyte_e);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
     } else {
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::b_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::b_piece_at(n);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
-      if (p >= 0) sq_issue_piece<CFG, 0>(rs_e, voff, stage_e, wave, p, kbyte_e);
+      if (p >= 0) sq_issue_piece<CFG, 0>(rs_e, voff_e, step_e, stage_e, wave, p, kbyte_e);
     }
   }
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-// One operand's LDS-DMA stream cursor: descriptor + per-lane offsets of the current work item's tile rows
-// and the K position inside it.  OP 0 = A (pieces 0 .. NJA-1 of voff), OP 1 = B (pieces NJA .. NJ-1).
-// Descriptors must be PROVABLY uniform (readfirstlane on the base pointer) or hipcc wraps every LDS-DMA in a
-// waterfall loop (see hgemm_kernel_sp.hpp).
+// One operand's LDS-DMA stream cursor: descriptor of the current work item's tile rows and the K position inside it.
+// OP 0 = A, OP 1 = B.  Descriptors must be PROVABLY uniform (readfirstlane on the base pointer) or hipcc wraps every
+// LDS-DMA in a waterfall loop (see hgemm_kernel_sp.hpp).  The range ends with the operand's last row (see sq_issue_piece).
 #define SQ_LOAD_ITEM(OP, ITEM)                                                                                 \
   do {                                                                                                         \
     /* the A stream crosses into an item first; the B stream reuses its tile coordinates (the raster map     \
@@ -278,16 +282,11 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
                                      : reinterpret_cast<uintptr_t>(g.Bt + (size_t)nxt_n0 * g.ldb);             \
     const uintptr_t uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) |     \
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);                       \
-    if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, 0xFFFFFFFFu, 0x00020000);            \
-    else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, 0xFFFFFFFFu, 0x00020000);            \
-    _Pragma("unroll") for (int j_ = ((OP) == 0 ? 0 : CFG::PA); j_ < ((OP) == 0 ? CFG::PA : NJ); ++j_) {        \
-      const int il_ = (OP) == 0 ? wave + j_ * CFG::NW : wave + j_ * CFG::NW - CFG::NI_A;                       \
-      const int r_ = il_ * 8 + (lane >> 3);                                                                    \
-      const int rmax_ = (OP) == 0 ? (g.M - 1 - nxt_m0) : (g.N - 1 - nxt_n0);                                   \
-      const int ld_ = (OP) == 0 ? g.lda : g.ldb;                                                               \
-      const int chunk_ = (lane & 7) ^ (((il_ & 1) << 2) | (lane >> 4));                                        \
-      voff[j_] = ((uint32_t)min(r_, rmax_) * (uint32_t)ld_ + (uint32_t)chunk_ * 8u) * 2u;                      \
-    }                                                                                                          \
+    const unsigned long long rows_ = (OP) == 0 ? (unsigned long long)(g.M - nxt_m0) : (unsigned long long)(g.N - nxt_n0); \
+    const unsigned long long rem_ = rows_ * (unsigned long long)((OP) == 0 ? g.lda : g.ldb) * 2ull;            \
+    const unsigned range_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(rem_ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)rem_)); \
+    if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
+    else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
     {                                                                                                          \
       const int s0_ = (HGEMM_SQ_XSTAGGER && nxt_nk >= 8) ? (int)(blockIdx.x % NUM_XCD) * (nxt_nk / NUM_XCD) : 0; \
       cur[OP].kbyte = (uint32_t)nxt_kb + (uint32_t)s0_ * (CFG::KT * ROW_BYTES);                                \
@@ -329,12 +328,12 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
     char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                           \
     char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                     \
     sq_interval<CFG, 0>(fX, fU, fV, SQ_FRAG(st, b_base_off, 1, 0), SQ_FRAG(st, b_base_off, 1, 1),               \
-                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), voff, wave,         \
-                        rsA, st, cur[0].kbyte, rsB, st, cur[1].kbyte);                                          \
+                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), wave,               \
+                        rsA, voffA, stepA, st, cur[0].kbyte, rsB, voffB, stepB, st, cur[1].kbyte);              \
     ADV0;                                                                                                       \
     sq_interval<CFG, 1>(YS, fV, fX, SQ_FRAG(nst, a_base_off, 0, 0), SQ_FRAG(nst, a_base_off, 0, 1),             \
-                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), voff, wave,         \
-                        rsB, st, cur[1].kbyte, rsA, nst, cur[0].kbyte);                                         \
+                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), wave,               \
+                        rsB, voffB, stepB, st, cur[1].kbyte, rsA, voffA, stepA, nst, cur[0].kbyte);             \
     ADV1;                                                                                                       \
     ++step;                                                                                                     \
   } while (0)
@@ -379,7 +378,14 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 
   // ---- the two LDS-DMA streams (A: three tiles ahead of the MFMAs, B: two) ---------------------------------
   __amdgpu_buffer_rsrc_t rsA, rsB;
-  uint32_t voff[NJ];
+  // per-lane source offset of this lane inside the wave's FIRST 8-row block of an operand (row wave * 8 + lane / 8; the
+  // 16-B chunk is the LDS image's swizzle, keyed on the row block's parity = the wave's, NW being even) and the scalar
+  // distance between two of the wave's row blocks: the same for every work item of the launch
+  static_assert(CFG::NW % 2 == 0, "the swizzle key of a wave's row blocks must not depend on the piece");
+  const uint32_t chunk0 = (uint32_t)((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4)));
+  const uint32_t voffA = ((uint32_t)(wave * 8 + (lane >> 3)) * (uint32_t)g.lda + chunk0 * 8u) * 2u;
+  const uint32_t voffB = ((uint32_t)(wave * 8 + (lane >> 3)) * (uint32_t)g.ldb + chunk0 * 8u) * 2u;
+  const uint32_t stepA = (uint32_t)g.lda * (CFG::NW * 8 * 2), stepB = (uint32_t)g.ldb * (CFG::NW * 8 * 2);
   struct Cursor { uint32_t kbyte; int item, kt, nk, wrap_kt; } cur[2];
   int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
   SQ_LOAD_ITEM(0, 0);
@@ -388,9 +394,9 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
+    for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, stepA, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
 #pragma unroll
-    for (int p = 0; p < CFG::NJB; ++p) sq_issue_piece<CFG, 1>(rsB, voff, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
+    for (int p = 0; p < CFG::NJB; ++p) sq_issue_piece<CFG, 1>(rsB, voffB, stepB, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
     SQ_ADVANCE(0);
     SQ_ADVANCE(1);
   }
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   sp_sync();
 #pragma unroll
-  for (int p = 0; p < CFG::DA; ++p) sq_issue_piece<CFG, 0>(rsA, voff, smem, wave, p, cur[0].kbyte);
+  for (int p = 0; p < CFG::DA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, stepA, smem, wave, p, cur[0].kbyte);
 
   int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
   HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 2, tid);

@@ -37,8 +37,11 @@ class Geometry:
         self.STAGE_BYTES = (bm + bn) * ROW_BYTES
 
 
-def stage_tile(geo: Geometry, a_tile: np.ndarray, bt_tile: np.ndarray, k0: int, m_valid: int, n_valid: int) -> np.ndarray:
-    """LDS image (in halfs) of one K-step; a_tile [rows>=..][K], bt_tile likewise (tile-local rows)."""
+def stage_tile(geo: Geometry, a_tile: np.ndarray, bt_tile: np.ndarray, k0: int, m_valid: int, n_valid: int, oob_zero: bool = False) -> np.ndarray:
+    """LDS image (in halfs) of one K-step; a_tile [rows>=..][K], bt_tile likewise (tile-local rows).
+    Rows past the M / N edge: the classic / s families clamp them to the last valid row (per-piece lane offsets); family q
+    (round 3: one lane offset per operand + a scalar row-block step, descriptor range = the rest of the matrix) reads
+    them out of range, i.e. as zeros (oob_zero).  Either way they only feed accumulators that are never stored."""
     lds = np.full(geo.STAGE_BYTES // 2, np.nan, dtype=np.float32)
     for wave in range(geo.NW):
         for j in range(geo.NJ):
@@ -54,6 +57,13 @@ def stage_tile(geo: Geometry, a_tile: np.ndarray, bt_tile: np.ndarray, k0: int, 
                 chunk = (lane & 7) ^ (((il & 1) << 2) | (lane >> 4))
                 src = a_tile if is_a else bt_tile
                 vals = src[rc, k0 + chunk * 8: k0 + chunk * 8 + 8]
+                if oob_zero:
+                    # family q: offset = lane part (row wave * 8 + lane / 8 of the wave's first block, chunk keyed on the
+                    # WAVE's parity) + scalar j * NW * 8 rows; the two forms must name the same row and chunk
+                    q = j if is_a else j - geo.NI_A // geo.NW
+                    assert geo.NW % 2 == 0 and il == wave + q * geo.NW and (il & 1) == (wave & 1)
+                    if r > rmax:
+                        vals = np.zeros(8, dtype=src.dtype)
                 dst = (i * 1024 + lane * 16) // 2
                 lds[dst:dst + 8] = vals
     return lds
@@ -113,7 +123,7 @@ def bank_conflict_extra_cycles(byte_addrs) -> int:
     return extra
 
 
-def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int):
+def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int, oob_zero: bool = False):
     """Compute the C tile at (m0, n0) the way the kernel does. Returns (C_tile dict, conflicts)."""
     M, K = A.shape
     N = Bt.shape[0]
@@ -126,7 +136,7 @@ def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int):
     acc = np.zeros((geo.NW, geo.FM, geo.FN, 64, nacc))
     conflicts = 0
     for k0 in range(0, K, BK):
-        lds = stage_tile(geo, a_tile, bt_tile, k0, M - m0, N - n0)
+        lds = stage_tile(geo, a_tile, bt_tile, k0, M - m0, N - n0, oob_zero)
         for wave in range(geo.NW):
             wave_m, wave_n = wave // geo.WN, wave % geo.WN
             a_row_base = wave_m * geo.TM * ROW_BYTES
