@@ -61,6 +61,19 @@
                               // the CU's one address path takes ~20 cycles per piece, four waves x one piece per 64 cycles
                               // saturates it behind every sync point while it idles in front of the next one.
 #endif
+#ifndef HGEMM_SQ_GAPS
+#define HGEMM_SQ_GAPS 1       // spread plan only.  One wave per SIMD: whatever sits between two MFMAs shares the 16 cycles of the
+                              // first one (about four issue slots, a VMEM or DS instruction takes two).  Round-3 timeline
+                              // ablation: the K-step costs 2284 cycles against 2070 for the bare MFMA stream, 180 of the
+                              // difference vanish with the LDS-DMA pieces although spreading them changes nothing -- what costs
+                              // is the gap that holds buffer_load + s_add m0 + s_add soffset, the one with ds_read between two
+                              // compiler-placed s_waitcnt, and the sync point's seven instructions.  1: (a) a piece is TWO asm
+                              // statements in two different gaps (s_add m0 one gap ahead of the buffer_load; per-piece lane
+                              // offsets instead of scalar ones, so no third instruction); (b) one lgkmcnt(0) the compiler can
+                              // see (builtin) near the end of every interval, after which it places no waits of its own in
+                              // front of the next interval's MFMAs; (c) the sync point's vmcnt wait sits one gap ahead of the
+                              // lgkmcnt wait + barrier.  The vendor kernel's loop has the same one-instruction-per-gap shape.
+#endif
 #ifndef HGEMM_SQ_ABL
 #define HGEMM_SQ_ABL 0        // measurement builds only (results are garbage): drop parts of the K loop to price them with the
                               // timeline stamps: 1 no s_barrier, 2 no vmcnt wait, 4 no lgkmcnt(0) at the sync points,
@@ -145,10 +158,13 @@ struct SqPlan {
   // ---- spread plan (HGEMM_SQ_SPREAD): PH = 0 interval A (sync slot P), 1 interval B (sync slot Q) -------------------
   // late piece k of E, in front of sync slot S: centred in its 1/E share of [0, S), on an odd slot when the leading reads
   // sit on the even ones
+  // (one-instruction-per-gap form: M0 is written one slot ahead, so slot 0 is out; the vmcnt wait of the sync point sits
+  // at slot S - 2 and counts on every late piece having been issued: nothing later than S - 3)
   static constexpr int late_slot(int k, int E, int S) {
     int x = ((2 * k + 1) * S) / (2 * E);
     if (CFG::RS == 2) x |= 1;
-    return x < S ? x : S - 1;
+    const int lo = 1 + k, hi = S - 3 - (E - 1 - k);
+    return x < lo ? lo : x > hi ? hi : x;
   }
   // trailing read i of N behind sync slot S: every second slot when they fit, else every slot
   static constexpr int trail_step(int N, int S) { return S + 1 + 2 * (N - 1) < T ? 2 : 1; }
@@ -178,7 +194,7 @@ struct SqPlan {
   template <int PH> static constexpr bool slots_ok() {        // every item has its own slot inside the interval
     const int S = sync_slot<PH>();
     for (int k = 0; k < n_late<PH>(); ++k) {
-      if (late_slot(k, n_late<PH>(), S) >= S) return false;
+      if (late_slot(k, n_late<PH>(), S) > S - 3 || late_slot(k, n_late<PH>(), S) < 1) return false;
       if (k && late_slot(k, n_late<PH>(), S) <= late_slot(k - 1, n_late<PH>(), S)) return false;
     }
     for (int k = 0; k < n_early<PH>(); ++k) {
@@ -190,23 +206,61 @@ struct SqPlan {
   static_assert(!HGEMM_SQ_SPREAD || (slots_ok<0>() && slots_ok<1>()), "spread slot plan does not fit the interval");
 };
 
+// The spread plan of one interval as tables indexed by the slot (the K loop's body is unrolled over the slots: a table
+// look-up with a constant index folds, the search loops of SqPlan::*_at would each be unrolled T times first and blow
+// the unroller's size budget).  -1 = nothing in this slot.
+template <class CFG, int PH>
+struct SqSlots {
+  signed char late[CFG::T + 1], early[CFG::T + 1], trail[CFG::T + 1];
+  constexpr SqSlots() : late(), early(), trail() {
+    using PL = SqPlan<CFG>;
+    for (int n = 0; n <= CFG::T; ++n) {
+      late[n] = (signed char)PL::template late_at<PH>(n);
+      early[n] = (signed char)PL::template early_at<PH>(n);
+      trail[n] = (signed char)PL::template trail_at<PH>(n);
+    }
+  }
+};
+
 // LDS-DMA piece `idx` (0 .. KT*P_op - 1) of operand OP for the stage at `stage`: sub-tile idx / P_op, 8-row
 // block idx % P_op of this wave; the source advances 128 B per sub-tile.
-// Addressing (round 3): ONE per-lane offset per operand (lane's row of the wave's first 8-row block, swizzled chunk)
-// for the whole kernel; the row block of a piece (wave + p * NW) is the scalar offset p * step, step = NW * 8 rows *
-// ld * 2 B; the descriptor starts at the tile's first row and ENDS WITH THE MATRIX, so rows past the M / N edge are out
-// of range and arrive as zeros.  Round 2 kept one clamped per-lane offset per piece (16 VGPRs, recomputed at every work
-// item with ~160 VALU operations, and held twice by the register allocator around the item seams).
+// Addressing (round 3): the per-lane offsets (lane's row of the wave's q-th 8-row block, swizzled chunk) are computed ONCE
+// per kernel -- they depend on the lane and the leading dimension only -- and the descriptor starts at the tile's first
+// row and ENDS WITH THE MATRIX, so rows past the M / N edge are out of range and arrive as zeros.  Round 2 clamped the
+// rows instead, which made the offsets depend on the work item: 16 VGPRs recomputed at every item seam with ~160 VALU
+// operations and held twice by the register allocator around the seams.
 template <class CFG, int OP>
-__device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t step, char* stage,
+__device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[OP == 0 ? CFG::PA : CFG::PB], char* stage,
                                                int wave, int idx, uint32_t kbyte) {
   constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
   const int sub = idx / POP, q = idx % POP, p = (OP == 0 ? 0 : CFG::PA) + q;
   lds_void_t* dst = (lds_void_t*)(stage + sub * CFG::SUB_BYTES + (wave + p * CFG::NW) * 1024);
   // (the sub-tile's 128 B go into the scalar offset: the instruction's immediate offset would also be added to
   // the LDS address of an LDS-DMA)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, kbyte + sub * ROW_BYTES + (uint32_t)q * step, 0, HGEMM_DMA_AUX);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff[q], kbyte + sub * ROW_BYTES, 0, HGEMM_DMA_AUX);
 }
+
+// HGEMM_SQ_GAPS form of a piece: the LDS destination goes into M0 in one gap, the load is issued in the next.  M0 is
+// the compiler's register; it has no use for it inside the K loops once every LDS-DMA there is one of these pairs (the
+// builtin form, which sets M0 itself, is only used outside them), and tests/test_build_audit.py checks on the ISA that
+// M0 writes and LDS-DMA loads strictly alternate in every MFMA loop.  An MFMA always sits between the two statements, which
+// covers the one wait state an LDS-DMA needs behind an M0 write.
+template <class CFG, int OP>
+__device__ __forceinline__ void sq_piece_m0(uint32_t wave_stage_lds, int idx) {
+  constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
+  const int sub = idx / POP, p = (OP == 0 ? 0 : CFG::PA) + idx % POP;
+  // (the sum as an "s" operand: the piece index is a constant only after unrolling, too late for an immediate constraint)
+  asm volatile("s_mov_b32 m0, %0" ::"s"(wave_stage_lds + (uint32_t)(sub * CFG::SUB_BYTES + p * CFG::NW * 1024)));
+}
+template <class CFG, int OP>
+__device__ __forceinline__ void sq_piece_load(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[OP == 0 ? CFG::PA : CFG::PB], int idx,
+                                              uint32_t kbyte) {
+  constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
+  const int sub = idx / POP, q = idx % POP;
+  static_assert(HGEMM_DMA_AUX == 0, "cache-policy experiments use the builtin form");
+  asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[q]), "s"(rs), "s"(kbyte + sub * ROW_BYTES) : "memory");
+}
+constexpr int kWaitLgkm0 = 0xC07F;   // s_waitcnt lgkmcnt(0) as the builtin's immediate (vmcnt 63, expcnt 7 = no wait)
 
 // One interval.  PHASE 0 = A(t): MFMAs af x bf; leading reads -> lead (B fragments of the second half of tile t);
 // behind P: B pieces of tile t+2 and trailing reads -> trail (A fragments of the second half of tile t+1).
@@ -220,18 +274,24 @@ template <class CFG, int PHASE>
 __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f16x8 (&bf)[CFG::NFB],
                                             f16x8 (&lead)[PHASE == 0 ? CFG::NFB : CFG::NFA], const char* lead0, const char* lead1,
                                             f16x8 (&trail)[PHASE == 0 ? CFG::NFA : CFG::NFB], const char* trail0, const char* trail1,
-                                            int wave,
-                                            __amdgpu_buffer_rsrc_t rs_l, uint32_t voff_l, uint32_t step_l, char* stage_l, uint32_t kbyte_l,
-                                            __amdgpu_buffer_rsrc_t rs_e, uint32_t voff_e, uint32_t step_e, char* stage_e, uint32_t kbyte_e) {
+                                            int wave, const uint32_t (&voffA)[CFG::PA], const uint32_t (&voffB)[CFG::PB],
+                                            __amdgpu_buffer_rsrc_t rs_l, char* stage_l, uint32_t kbyte_l,
+                                            __amdgpu_buffer_rsrc_t rs_e, char* stage_e, uint32_t kbyte_e) {
   using PL = SqPlan<CFG>;
   constexpr int FM = CFG::FM, FN = CFG::FN, T = CFG::T, RS = CFG::RS;
   constexpr int NLEAD = PHASE == 0 ? CFG::NFB : CFG::NFA, FLEAD = PHASE == 0 ? FN : FM, FTRAIL = PHASE == 0 ? FM : FN;
   constexpr int OP_E = PHASE == 0 ? 1 : 0, OP_L = PHASE == 0 ? 0 : 1;          // operand of the early / late pieces
   constexpr int D_L = PHASE == 0 ? CFG::DA : CFG::DB;                          // late pieces are D_L .. NJ_op - 1 of their half-tile
+  constexpr int S = PHASE == 0 ? CFG::P : CFG::Q;
+  constexpr bool GAPS = HGEMM_SQ_SPREAD && HGEMM_SQ_GAPS;
+  // LDS byte address of this wave's first 1-KiB block of the destination stages (GAPS: M0 = this + a constant per piece)
+  const uint32_t lds_l = (uint32_t)(uintptr_t)(lds_void_t*)stage_l + (uint32_t)wave * 1024u;
+  const uint32_t lds_e = (uint32_t)(uintptr_t)(lds_void_t*)stage_e + (uint32_t)wave * 1024u;
+  (void)lds_l; (void)lds_e;
 #pragma unroll
   for (int n = 0; n < T; ++n) {
     const int u = n / (FM * FN), i = (n / FN) % FM, j = n % FN;   // MFMA k-slice, accumulator tile (i, j)
-    if (n == (PHASE == 0 ? CFG::P : CFG::Q)) {
+    if (!GAPS && n == S) {
       // every fragment read of the region about to be refilled has RETURNED (LDS returns in order, and the
       // leading reads were the last ones issued), and my pieces of the half-tile the trailing reads are
       // about to consume have landed; two younger half-tiles may stay in flight
@@ -239,26 +299,49 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       if (!(HGEMM_SQ_ABL & 2)) wait_vmcnt<CFG::NJA + CFG::NJB>();
       if (!(HGEMM_SQ_ABL & 1)) sp_sync();
     }
+    if (GAPS && n == S) {   // (the vmcnt wait went out one gap earlier)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(HGEMM_SQ_ABL & 4)) __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
+      if (!(HGEMM_SQ_ABL & 1)) sp_sync();
+    }
     sp_mfma_mi<CFG::MI>(i * FN + j, bf[u * FN + j], af[u * FM + i]);
     if (!(HGEMM_SQ_ABL & 16) && n % RS == 0 && n / RS < NLEAD) {
       const int r = n / RS;
       lead[r] = *(const f16x8*)((r / FLEAD ? lead1 : lead0) + (r % FLEAD) * CFG::MI * ROW_BYTES);
     }
-    if constexpr (HGEMM_SQ_SPREAD) {
-      const int l = (HGEMM_SQ_ABL & 8) ? -1 : PL::template late_at<PHASE>(n);
-      const int e = (HGEMM_SQ_ABL & 8) ? -1 : PL::template early_at<PHASE>(n);
-      const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::template trail_at<PHASE>(n);
-      if (l >= 0) sq_issue_piece<CFG, OP_L>(rs_l, voff_l, step_l, stage_l, wave, D_L + l, kbyte_l);
+    if constexpr (GAPS) {
+      // gap n (behind MFMA n): at most one memory instruction besides a leading read; the M0 write of a piece one gap early
+      constexpr SqSlots<CFG, PHASE> tab{};
+      const int l = (HGEMM_SQ_ABL & 8) ? -1 : tab.late[n], l1 = (HGEMM_SQ_ABL & 8) ? -1 : tab.late[n + 1];
+      const int e = (HGEMM_SQ_ABL & 8) ? -1 : tab.early[n], e1 = (HGEMM_SQ_ABL & 8) ? -1 : tab.early[n + 1];
+      const int r = (HGEMM_SQ_ABL & 16) ? -1 : tab.trail[n];
+      if (l >= 0) { if constexpr (OP_L == 0) sq_piece_load<CFG, 0>(rs_l, voffA, D_L + l, kbyte_l); else sq_piece_load<CFG, 1>(rs_l, voffB, D_L + l, kbyte_l); }
+      if (e >= 0) { if constexpr (OP_E == 0) sq_piece_load<CFG, 0>(rs_e, voffA, e, kbyte_e); else sq_piece_load<CFG, 1>(rs_e, voffB, e, kbyte_e); }
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
-      if (e >= 0) sq_issue_piece<CFG, OP_E>(rs_e, voff_e, step_e, stage_e, wave, e, kbyte_e);
+      if (l1 >= 0) sq_piece_m0<CFG, OP_L>(lds_l, D_L + l1);
+      if (e1 >= 0) sq_piece_m0<CFG, OP_E>(lds_e, e1);
+      if (n == S - 2 && !(HGEMM_SQ_ABL & 2)) wait_vmcnt<CFG::NJA + CFG::NJB>();
+      if (n == T - 3) {   // every read of this interval has long returned: from here on the compiler knows it, too
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (HGEMM_SQ_SPREAD) {
+      constexpr SqSlots<CFG, PHASE> tab{};
+      const int l = (HGEMM_SQ_ABL & 8) ? -1 : tab.late[n];
+      const int e = (HGEMM_SQ_ABL & 8) ? -1 : tab.early[n];
+      const int r = (HGEMM_SQ_ABL & 16) ? -1 : tab.trail[n];
+      if (l >= 0) { if constexpr (OP_L == 0) sq_issue_piece<CFG, 0>(rs_l, voffA, stage_l, wave, D_L + l, kbyte_l); else sq_issue_piece<CFG, 1>(rs_l, voffB, stage_l, wave, D_L + l, kbyte_l); }
+      if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
+      if (e >= 0) { if constexpr (OP_E == 0) sq_issue_piece<CFG, 0>(rs_e, voffA, stage_e, wave, e, kbyte_e); else sq_issue_piece<CFG, 1>(rs_e, voffB, stage_e, wave, e, kbyte_e); }
     } else if (PHASE == 0) {
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::a_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::a_piece_at(n);
-      if (p >= 0) sq_issue_piece<CFG, 1>(rs_e, voff_e, step_e, stage_e, wave, p, kbyte_e);
+      if (p >= 0) { if constexpr (OP_E == 0) sq_issue_piece<CFG, 0>(rs_e, voffA, stage_e, wave, p, kbyte_e); else sq_issue_piece<CFG, 1>(rs_e, voffB, stage_e, wave, p, kbyte_e); }
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
     } else {
       const int r = (HGEMM_SQ_ABL & 16) ? -1 : PL::b_read_at(n), p = (HGEMM_SQ_ABL & 8) ? -1 : PL::b_piece_at(n);
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
-      if (p >= 0) sq_issue_piece<CFG, 0>(rs_e, voff_e, step_e, stage_e, wave, p, kbyte_e);
+      if (p >= 0) { if constexpr (OP_E == 0) sq_issue_piece<CFG, 0>(rs_e, voffA, stage_e, wave, p, kbyte_e); else sq_issue_piece<CFG, 1>(rs_e, voffB, stage_e, wave, p, kbyte_e); }
     }
   }
 }
@@ -328,12 +411,12 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
     char* st  = smem + (step & 1) * CFG::STAGE_BYTES;                                                           \
     char* nst = smem + ((step + 1) & 1) * CFG::STAGE_BYTES;                                                     \
     sq_interval<CFG, 0>(fX, fU, fV, SQ_FRAG(st, b_base_off, 1, 0), SQ_FRAG(st, b_base_off, 1, 1),               \
-                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), wave,               \
-                        rsA, voffA, stepA, st, cur[0].kbyte, rsB, voffB, stepB, st, cur[1].kbyte);              \
+                        ZS, SQ_FRAG(nst, a_base_off, 1, 0), SQ_FRAG(nst, a_base_off, 1, 1), wave, voffA, voffB, \
+                        rsA, st, cur[0].kbyte, rsB, st, cur[1].kbyte);                                          \
     ADV0;                                                                                                       \
     sq_interval<CFG, 1>(YS, fV, fX, SQ_FRAG(nst, a_base_off, 0, 0), SQ_FRAG(nst, a_base_off, 0, 1),             \
-                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), wave,               \
-                        rsB, voffB, stepB, st, cur[1].kbyte, rsA, voffA, stepA, nst, cur[0].kbyte);             \
+                        fU, SQ_FRAG(nst, b_base_off, 0, 0), SQ_FRAG(nst, b_base_off, 0, 1), wave, voffA, voffB, \
+                        rsB, st, cur[1].kbyte, rsA, nst, cur[0].kbyte);                                         \
     ADV1;                                                                                                       \
     ++step;                                                                                                     \
   } while (0)
@@ -378,14 +461,16 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 
   // ---- the two LDS-DMA streams (A: three tiles ahead of the MFMAs, B: two) ---------------------------------
   __amdgpu_buffer_rsrc_t rsA, rsB;
-  // per-lane source offset of this lane inside the wave's FIRST 8-row block of an operand (row wave * 8 + lane / 8; the
-  // 16-B chunk is the LDS image's swizzle, keyed on the row block's parity = the wave's, NW being even) and the scalar
-  // distance between two of the wave's row blocks: the same for every work item of the launch
+  // per-lane source offsets: lane's row of the wave's q-th 8-row block (row (wave + q * NW) * 8 + lane / 8; the 16-B chunk
+  // is the LDS image's swizzle, keyed on the row block's parity = the wave's, NW being even): the same for every work
+  // item of the launch
   static_assert(CFG::NW % 2 == 0, "the swizzle key of a wave's row blocks must not depend on the piece");
   const uint32_t chunk0 = (uint32_t)((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4)));
-  const uint32_t voffA = ((uint32_t)(wave * 8 + (lane >> 3)) * (uint32_t)g.lda + chunk0 * 8u) * 2u;
-  const uint32_t voffB = ((uint32_t)(wave * 8 + (lane >> 3)) * (uint32_t)g.ldb + chunk0 * 8u) * 2u;
-  const uint32_t stepA = (uint32_t)g.lda * (CFG::NW * 8 * 2), stepB = (uint32_t)g.ldb * (CFG::NW * 8 * 2);
+  uint32_t voffA[CFG::PA], voffB[CFG::PB];
+#pragma unroll
+  for (int q = 0; q < CFG::PA; ++q) voffA[q] = ((uint32_t)((wave + q * CFG::NW) * 8 + (lane >> 3)) * (uint32_t)g.lda + chunk0 * 8u) * 2u;
+#pragma unroll
+  for (int q = 0; q < CFG::PB; ++q) voffB[q] = ((uint32_t)((wave + q * CFG::NW) * 8 + (lane >> 3)) * (uint32_t)g.ldb + chunk0 * 8u) * 2u;
   struct Cursor { uint32_t kbyte; int item, kt, nk, wrap_kt; } cur[2];
   int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
   SQ_LOAD_ITEM(0, 0);
@@ -394,9 +479,9 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, stepA, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
+    for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
 #pragma unroll
-    for (int p = 0; p < CFG::NJB; ++p) sq_issue_piece<CFG, 1>(rsB, voffB, stepB, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
+    for (int p = 0; p < CFG::NJB; ++p) sq_issue_piece<CFG, 1>(rsB, voffB, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
     SQ_ADVANCE(0);
     SQ_ADVANCE(1);
   }
@@ -417,10 +502,11 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   for (int r = 0; r < NFB; ++r) fU[r] = *(const f16x8*)(SQ_FRAG(smem, b_base_off, 0, r / FN) + (r % FN) * MI * ROW_BYTES);
   // the A region of stage 0 is consumed: the early pieces of A(2) go there (sync = the "Q" of a virtual K-step -1); its late
   // pieces follow in interval A of the first K-step, which then moves the A stream on
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(kWaitLgkm0);   // (the builtin form: the compiler then places no waits of its own in the K loop)
   sp_sync();
 #pragma unroll
-  for (int p = 0; p < CFG::DA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, stepA, smem, wave, p, cur[0].kbyte);
+  for (int p = 0; p < CFG::DA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, smem, wave, p, cur[0].kbyte);
 
   int step = 0;               // global K-step of this workgroup's stream: stage = step & 1
   HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 2, tid);

@@ -300,7 +300,7 @@ def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, r
             x = ((2 * k + 1) * S) // (2 * E)
             if RS == 2:
                 x |= 1
-            out.append(min(x, S - 1))
+            out.append(max(1 + k, min(x, S - 3 - (E - 1 - k))))      # M0 one slot ahead; vmcnt wait at S - 2
         return out
 
     def trail(N, S):
@@ -317,39 +317,46 @@ def sq_plan(FM: int, FN: int, PA: int, PB: int, KT: int = 1, slack64: int = 6, r
         return out
 
     # interval A: late A pieces, sync P, trailing A-fragment reads, early B pieces; interval B: late B, Q, B reads, early A
-    return dict(base, EA=EA, EB=EB, late_A=late(EA, P), late_B=late(EB, Q),
+    return dict(base, gaps=True, EA=EA, EB=EB, late_A=late(EA, P), late_B=late(EB, Q),
                 reads_A=trail(NFA, P), pieces_A=early(NJB - EB, P), reads_B=trail(NFB, Q), pieces_B=early(NJA - EA, Q))
 
 
 def sq_schedule_hazards(plan: dict, steps: int = 8):
     """Replay one wave's instruction stream of family q for `steps` pipeline stages and check every LDS hazard with
-    the kernel's own ordering rules.  Regions: ("A", s) / ("B", s) of stage s in {0, 1}.  Rules:
-      RAW  a fragment read of tile t from a region must come behind a sync point (counted vmcnt + barrier) whose wait
-           covers every DMA piece of tile t into that region.  s_waitcnt vmcnt(N) returns with at most the N YOUNGEST
-           pieces outstanding (they complete in order), so a piece is guaranteed to have landed iff at least N pieces
-           were issued after it before the sync;
-      WAR  a DMA piece into a region must come behind a sync point (lgkmcnt(0) + barrier) that follows every read of
-           the region's previous occupant (tile t-2).
-    All four waves run the same stream and leave a sync point together, so one stream is enough.  Returns a list of
-    violations (empty = the plan is hazard-free).  Every tile must also receive exactly its NJ pieces."""
+    the kernel's own ordering rules.  Regions: ("A", s) / ("B", s) of stage s in {0, 1}.  Events: "vm" = a counted
+    s_waitcnt vmcnt(N) of the wave, "bar" = lgkmcnt(0) + s_barrier (all four waves run the same stream and leave a
+    barrier together, so one stream is enough).  Rules:
+      RAW  a fragment read of tile t from a region must come behind a "bar" that itself follows (or coincides with) a "vm"
+           whose count covers every DMA piece of tile t into that region: the wait makes the waiting wave's own pieces
+           visible, the barrier behind it everybody's.  s_waitcnt vmcnt(N) returns with at most the N YOUNGEST pieces
+           outstanding (they complete in order), so a piece is guaranteed to have landed iff at least N pieces were
+           issued after it BEFORE THE WAIT;
+      WAR  a DMA piece into a region must come behind a "bar" that follows every read of the region's previous occupant
+           (tile t-2).
+    The round-2 plan and the plain spread plan wait and synchronise in one slot; the one-instruction-per-gap form
+    (plan["gaps"]) waits for vmcnt two slots ahead of the barrier.  Returns a list of violations (empty = hazard-free).
+    Every tile must also receive exactly its NJ pieces."""
     T, NJA, NJB = plan["T"], plan["NJA"], plan["NJB"]
-    EA, EB = plan.get("EA", 0), plan.get("EB", 0)
-    events = []   # (time, kind, operand, tile); time = (interval index) * (T + 1) + slot, sync sorts before its slot's MFMA
+    EA = plan.get("EA", 0)
+    vm_lead = 2 if plan.get("gaps") else 0
+    events = []   # (time, kind, arg, tile); a sync sorts before its slot's MFMA (half 0), the slot's other items behind it
 
     def at(interval, slot, half=0):
         return interval * 2 * (T + 2) + slot * 2 + half
 
-    # prologue: pieces of tiles 0, 1 (A then B each), sync, reads of tile 0 (A both halves, B first half), sync, early A(2)
+    # prologue: pieces of tiles 0, 1 (A then B each), wait + barrier, reads of tile 0 (A both halves, B first half),
+    # lgkmcnt(0) + barrier, early A(2)
     t0 = -10 * (T + 2)
     order = 0
     for tile in (0, 1):
         for op, n in (("A", NJA), ("B", NJB)):
             for _ in range(n):
                 events.append((t0 + order, "dma", op, tile)); order += 1
-    events.append((t0 + order, "sync_vm", NJA + NJB, None)); order += 1      # wait_vmcnt<NJA + NJB>: tile 0 landed
+    events.append((t0 + order, "vm", NJA + NJB, None)); order += 1           # wait_vmcnt<NJA + NJB>: tile 0 landed
+    events.append((t0 + order, "bar", None, None)); order += 1
     for op, half in (("A", 0), ("A", 1), ("B", 0)):
         events.append((t0 + order, "read", op, (0, half))); order += 1
-    events.append((t0 + order, "sync_lgkm", None, None)); order += 1
+    events.append((t0 + order, "bar", None, None)); order += 1
     for _ in range(NJA - EA):
         events.append((t0 + order, "dma", "A", 2)); order += 1
     for t in range(steps):
@@ -358,7 +365,8 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
             events.append((at(ia, s, 1), "read", "B", (t, 1)))
         for s in plan.get("late_A", []):
             events.append((at(ia, s, 1), "dma", "A", t + 2))     # the A stream still points at tile t+2 here
-        events.append((at(ia, plan["P"], 0), "sync_both", NJA + NJB, None))
+        events.append((at(ia, plan["P"] - vm_lead, 1 if vm_lead else 0) + (1 if vm_lead else 0), "vm", NJA + NJB, None))
+        events.append((at(ia, plan["P"], 0) + (0 if vm_lead else 0.5), "bar", None, None))
         for s in plan["pieces_A"]:
             events.append((at(ia, s, 1), "dma", "B", t + 2))
         for s in plan["reads_A"]:
@@ -367,7 +375,8 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
             events.append((at(ib, s, 1), "read", "A", (t + 1, 0)))
         for s in plan.get("late_B", []):
             events.append((at(ib, s, 1), "dma", "B", t + 2))
-        events.append((at(ib, plan["Q"], 0), "sync_both", NJA + NJB, None))
+        events.append((at(ib, plan["Q"] - vm_lead, 1 if vm_lead else 0) + (1 if vm_lead else 0), "vm", NJA + NJB, None))
+        events.append((at(ib, plan["Q"], 0) + (0 if vm_lead else 0.5), "bar", None, None))
         for s in plan["reads_B"]:
             events.append((at(ib, s, 1), "read", "B", (t + 1, 0)))
         for s in plan["pieces_B"]:
@@ -375,6 +384,8 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
     events.sort(key=lambda e: e[0])
     bad = []
     dmas = [e for e in events if e[1] == "dma"]
+    vms = [e for e in events if e[1] == "vm"]
+    bars = [e[0] for e in events if e[1] == "bar"]
     for op, nj in (("A", NJA), ("B", NJB)):
         for tile in range(2, steps + 1):
             got = sum(1 for e in dmas if e[2] == op and e[3] == tile)
@@ -383,16 +394,12 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
     for time, kind, op, what in events:
         if kind == "read":
             tile = what[0]
-            mine = [e for e in dmas if e[2] == op and e[3] == tile]
-            last_piece = max(e[0] for e in mine)
-            # a sync with a vmcnt wait, between the last piece and this read, at which >= arg younger pieces were in the queue
+            last_piece = max(e[0] for e in dmas if e[2] == op and e[3] == tile)
             ok = False
-            for st, sk, arg, _ in events:
-                if sk in ("sync_vm", "sync_both") and last_piece < st < time:
-                    younger = sum(1 for e in dmas if last_piece < e[0] < st)
-                    if younger >= arg:
-                        ok = True
-                        break
+            for wt, _, arg, _ in vms:
+                if last_piece < wt < time and sum(1 for e in dmas if last_piece < e[0] < wt) >= arg and any(wt <= b < time for b in bars):
+                    ok = True
+                    break
             if not ok:
                 bad.append(("RAW", op, what, time))
         if kind == "dma" and what >= 2:
@@ -401,7 +408,7 @@ def sq_schedule_hazards(plan: dict, steps: int = 8):
                 bad.append(("WAR: previous occupant was never read", op, what, time))
                 continue
             last_read = max(e[0] for e in prev_reads)
-            if not any(sk in ("sync_lgkm", "sync_both") and last_read < st < time for st, sk, _, _ in events):
+            if not any(last_read < b < time for b in bars):
                 bad.append(("WAR", op, what, time))
     return bad
 

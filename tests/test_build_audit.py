@@ -99,4 +99,41 @@ def test_sp_k_loops_are_mfma_streams_with_scalar_dma_descriptors(sp_functions):
         assert not [ln for ln in body if re.search(r"v_readfirstlane|s_and_saveexec|s_cbranch_execn?z", ln)], name
         # fragment registers are written by ds_read only; no VALU moves between the MFMAs
         assert not [ln for ln in body if re.search(r"\bv_mov_b32|\bv_accvgpr", ln)], name
-        assert len([ln for ln in body if "buffer_load_dwordx4" in ln and " lds" in ln]) >= 8, name
+        # (family q writes its LDS-DMA loads as asm statements, so they are counted on the whole loop text)
+        assert len([ln for ln in hot.splitlines() if "buffer_load_dwordx4" in ln and " lds" in ln.split(";")[0]]) >= 8, name
+
+
+def test_m0_writes_and_lds_dma_loads_alternate_in_the_k_loops(sp_functions):
+    """Family q issues an LDS-DMA piece as two asm statements in two MFMA gaps (hgemm_kernel_sq.hpp, HGEMM_SQ_GAPS): M0 = the
+    LDS destination, then the load.  M0 is the compiler's register, so the pairing is checked where it counts, on the ISA:
+    in every MFMA loop of the q kernels an M0 write is followed by exactly one LDS-DMA load before the next M0 write,
+    the loop neither starts with a load nor ends with a dangling M0 write, and at least one MFMA sits between the two
+    (the wait state an LDS-DMA needs behind an M0 write)."""
+    funcs, _ = sp_functions
+    checked = 0
+    for name, lines in funcs.items():
+        if "sq_kernel" not in name:
+            continue
+        text = "\n".join(lines)
+        for loop in re.split(r"This Inner Loop Header", text)[1:]:
+            body = loop.split("s_cbranch_scc")[0]
+            if len(re.findall(r"\bv_mfma_", body)) < 32:
+                continue
+            events = []
+            for ln in body.splitlines():
+                code = ln.split(";")[0].strip()
+                if re.match(r"s_\w+\s+m0\b", code):
+                    events.append("m0")
+                elif code.startswith("buffer_load_dwordx4") and code.endswith(" lds"):
+                    events.append("dma")
+                elif code.startswith("v_mfma_") and events and events[-1] == "m0":
+                    events.append("mfma")
+            seq = [e for e in events if e != "mfma"]
+            assert seq and seq[0] == "m0" and seq[-1] == "dma", f"{name}: {seq[:4]} ... {seq[-4:]}"
+            assert all(a != b for a, b in zip(seq, seq[1:])), f"{name}: M0 writes and LDS-DMA loads do not alternate"
+            # an MFMA between every M0 write and its load
+            for i, e in enumerate(events):
+                if e == "m0":
+                    assert events[i + 1] == "mfma", f"{name}: LDS-DMA right behind its M0 write"
+            checked += 1
+    assert checked >= 6

@@ -211,6 +211,11 @@ def test_family_q_hazard_model_catches_a_misplaced_wait():
     assert any(v[0] == "PIECES" for v in klm.sq_schedule_hazards(lost))
     wrong_window = dict(plan, late_B=[], pieces_A=plan["pieces_A"] + [0] * len(plan["late_B"]))
     assert any(v[0] in ("WAR", "RAW") for v in klm.sq_schedule_hazards(wrong_window))
+    # one-instruction-per-gap form: the vmcnt wait sits two slots ahead of the barrier; a late piece issued behind the wait
+    # is one younger piece short at the wait, which then no longer proves that the half-tile read next has landed
+    assert plan["gaps"]
+    behind_wait = dict(plan, late_A=plan["late_A"][:-1] + [plan["P"] - 1])
+    assert any(v[0] == "RAW" for v in klm.sq_schedule_hazards(behind_wait))
 
 
 def test_fused_split_k_slab_layout_is_a_bijection():
