@@ -51,10 +51,13 @@ constexpr int NUM_XCD   = 8;
 #ifndef HGEMM_NT_STORE
 #define HGEMM_NT_STORE 0
 #endif
+// (HGEMM_NT_STORE=1 forces them for every plan: experiment builds.  Shipping builds take the plan's HGEMM_PLAN_NT_STORE bit,
+// GemmArgs::flags bit 0 -- a wave-uniform branch around the store.)
 #if HGEMM_NT_STORE
-#define HGEMM_STORE_C(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define HGEMM_STORE_C(g, ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
-#define HGEMM_STORE_C(ptr, val) (*(ptr) = (val))
+#define HGEMM_STORE_C(g, ptr, val) \
+  do { if ((g).flags & 1) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 #endif
 
 #ifndef HGEMM_DMA_AUX
@@ -147,6 +150,7 @@ struct GemmArgs {
   // Single-launch split-K (EPI_FUSED): one arrival counter per output tile (zero before the launch, reset
   // by the last arriver) and compact per-item slabs partial[item][BM*BN] in the kernel's own lane order.
   unsigned* counters;
+  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE)
 #if HGEMM_FASTDIV
   RasterDiv rd;    // multipliers for the raster map's divisions (set_raster_div on the host, after the fields above are final)
 #endif
@@ -363,7 +367,7 @@ __device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoor
         if (m < g.M && n < g.N) {
           using u4 = __attribute__((ext_vector_type(4))) unsigned;
           const u4 o = {r0[0], r1[0], r0[1], r1[1]};
-          HGEMM_STORE_C((u4*)(g.C + (size_t)m * g.ldc + n), o);
+          HGEMM_STORE_C(g, (u4*)(g.C + (size_t)m * g.ldc + n), o);
         }
       }
       return;
@@ -386,7 +390,7 @@ __device__ __forceinline__ void store_tile_row(const GemmArgs& g, const TileCoor
         } else {
           f16* dst = g.C + (size_t)m * g.ldc + n;
           f16x4 o = {(f16)row[j][q * 4 + 0], (f16)row[j][q * 4 + 1], (f16)row[j][q * 4 + 2], (f16)row[j][q * 4 + 3]};
-          HGEMM_STORE_C((f16x4*)dst, o);
+          HGEMM_STORE_C(g, (f16x4*)dst, o);
         }
       }
     }

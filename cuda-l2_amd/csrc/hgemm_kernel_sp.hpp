@@ -297,7 +297,7 @@ __device__ __forceinline__ void sp_store_tile32(const GemmArgs& g, int m, int nb
       if (m < g.M && n < g.N) {
         using u4 = __attribute__((ext_vector_type(4))) unsigned;
         const u4 o = {r0[0], r1[0], r0[1], r1[1]};
-        HGEMM_STORE_C((u4*)(g.C + (size_t)m * g.ldc + n), o);
+        HGEMM_STORE_C(g, (u4*)(g.C + (size_t)m * g.ldc + n), o);
       }
     }
   } else {
@@ -306,7 +306,7 @@ __device__ __forceinline__ void sp_store_tile32(const GemmArgs& g, int m, int nb
       const int n = nb + 8 * q + 4 * (lane >> 5);
       if (m < g.M && n < g.N) {
         const f16x4 o = {(f16)qd[q][0], (f16)qd[q][1], (f16)qd[q][2], (f16)qd[q][3]};
-        HGEMM_STORE_C((f16x4*)(g.C + (size_t)m * g.ldc + n), o);
+        HGEMM_STORE_C(g, (f16x4*)(g.C + (size_t)m * g.ldc + n), o);
       }
     }
   }
@@ -328,9 +328,12 @@ __device__ __forceinline__ void sp_store_tile32(const GemmArgs& g, int m, int nb
 #define HGEMM_EPI_STAGED 1
 #endif
 constexpr int SP_STAGED_BYTES_PER_WAVE = 4096;
+// (only where the extra 16 KiB do not cost a resident workgroup: the host launches 256 x (160 KiB / (stages + 64 B)) of them)
 template <class CFG>
 constexpr bool sp_staged_ok(int lds_bytes) {
-  return HGEMM_EPI_STAGED && CFG::MI == 16 && CFG::FN % 4 == 0 && lds_bytes + 64 + CFG::NW * SP_STAGED_BYTES_PER_WAVE <= 160 * 1024;
+  return HGEMM_EPI_STAGED && CFG::MI == 16 && CFG::FN % 4 == 0 &&
+         (160 * 1024) / (lds_bytes + 64 + CFG::NW * SP_STAGED_BYTES_PER_WAVE) == (160 * 1024) / (lds_bytes + 64) &&
+         (160 * 1024) / (lds_bytes + 64) >= 1;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 // whole wave tile (FM fragment rows x FN tiles) -> C; `stage` = this wave's 4 KiB.  Accumulators are re-zeroed behind the
@@ -366,6 +369,7 @@ __device__ __forceinline__ void sp_epilogue_staged(const GemmArgs& g, int m_wave
   for (int gg = 0; gg < NG; ++gg)
     voff[gg] = (n_wave + gg * 64 + rch * 8 < g.N) ? (unsigned)(rrow * g.ldc + gg * 64 + rch * 8) * 2u : 0x80000000u;
   const unsigned row8 = (unsigned)g.ldc * 16u;                                          // 8 rows further, in bytes
+  const bool nt = (g.flags & 1) != 0;                                                   // plan flag HGEMM_PLAN_NT_STORE (uniform)
   u4 rb[2][2];   // read-back data of the group in flight [buffer][row half]
   auto write_group = [&](int k) {      // accumulators of group k -> buffer k & 1
     const int i = k / NG, gg = k % NG;
@@ -396,8 +400,10 @@ __device__ __forceinline__ void sp_epilogue_staged(const GemmArgs& g, int m_wave
     else               asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[b][0]), "+v"(rb[b][1])::"memory");
     if (HGEMM_DBG(g, 2)) return;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      __builtin_amdgcn_raw_buffer_store_b128(rb[b][h], rsC, voff[gg], (unsigned)(i * 2 + h) * row8, HGEMM_NT_STORE ? 2 : 0);
+    for (int h = 0; h < 2; ++h) {
+      if (HGEMM_NT_STORE || nt) __builtin_amdgcn_raw_buffer_store_b128(rb[b][h], rsC, voff[gg], (unsigned)(i * 2 + h) * row8, 2);
+      else                      __builtin_amdgcn_raw_buffer_store_b128(rb[b][h], rsC, voff[gg], (unsigned)(i * 2 + h) * row8, 0);
+    }
   };
   write_group(0);
 #pragma unroll

@@ -245,12 +245,18 @@ __device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, const 
 // builtin form, which sets M0 itself, is only used outside them), and tests/test_build_audit.py checks on the ISA that
 // M0 writes and LDS-DMA loads strictly alternate in every MFMA loop.  An MFMA always sits between the two statements, which
 // covers the one wait state an LDS-DMA needs behind an M0 write.
+// `cont`: the previous piece of this window was idx - 1 in the same sub-tile, so M0 only moves on by one row block of the
+// four waves (one instruction instead of an address computation + a move).
 template <class CFG, int OP>
-__device__ __forceinline__ void sq_piece_m0(uint32_t wave_stage_lds, int idx) {
+__device__ __forceinline__ void sq_piece_m0(uint32_t wave_stage_lds, int idx, bool cont) {
   constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
   const int sub = idx / POP, p = (OP == 0 ? 0 : CFG::PA) + idx % POP;
-  // (the sum as an "s" operand: the piece index is a constant only after unrolling, too late for an immediate constraint)
-  asm volatile("s_mov_b32 m0, %0" ::"s"(wave_stage_lds + (uint32_t)(sub * CFG::SUB_BYTES + p * CFG::NW * 1024)));
+  if (cont && idx % POP != 0) {
+    asm volatile("s_add_u32 m0, m0, %0" ::"n"(CFG::NW * 1024));
+  } else {
+    // (the sum as an "s" operand: the piece index is a constant only after unrolling, too late for an immediate constraint)
+    asm volatile("s_mov_b32 m0, %0" ::"s"(wave_stage_lds + (uint32_t)(sub * CFG::SUB_BYTES + p * CFG::NW * 1024)));
+  }
 }
 template <class CFG, int OP>
 __device__ __forceinline__ void sq_piece_load(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[OP == 0 ? CFG::PA : CFG::PB], int idx,
@@ -318,8 +324,8 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       if (l >= 0) { if constexpr (OP_L == 0) sq_piece_load<CFG, 0>(rs_l, voffA, D_L + l, kbyte_l); else sq_piece_load<CFG, 1>(rs_l, voffB, D_L + l, kbyte_l); }
       if (e >= 0) { if constexpr (OP_E == 0) sq_piece_load<CFG, 0>(rs_e, voffA, e, kbyte_e); else sq_piece_load<CFG, 1>(rs_e, voffB, e, kbyte_e); }
       if (r >= 0) trail[r] = *(const f16x8*)((r / FTRAIL ? trail1 : trail0) + (r % FTRAIL) * CFG::MI * ROW_BYTES);
-      if (l1 >= 0) sq_piece_m0<CFG, OP_L>(lds_l, D_L + l1);
-      if (e1 >= 0) sq_piece_m0<CFG, OP_E>(lds_e, e1);
+      if (l1 >= 0) sq_piece_m0<CFG, OP_L>(lds_l, D_L + l1, l1 > 0);
+      if (e1 >= 0) sq_piece_m0<CFG, OP_E>(lds_e, e1, e1 > 0);
       if (n == S - 2 && !(HGEMM_SQ_ABL & 2)) wait_vmcnt<CFG::NJA + CFG::NJB>();
       if (n == T - 3) {   // every read of this interval has long returned: from here on the compiler knows it, too
         __builtin_amdgcn_sched_barrier(0);
@@ -431,7 +437,13 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 
   // the two stages + one word for the single-launch split-K vote (ONE LDS object, see hgemm_kernel_sp.hpp)
   constexpr bool STAGED = EPI == SP_EPI_WIDE && sp_staged_ok<CFG>(CFG::LDS_BYTES);   // + 4 KiB per wave for the epilogue
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64 + (STAGED ? CFG::NW * SP_STAGED_BYTES_PER_WAVE : 0)];
+#ifdef HGEMM_TIMELINE
+  constexpr int TL_EXTRA = 64;   // measurement build: eight more stamp slots behind everything else
+#else
+  constexpr int TL_EXTRA = 0;
+#endif
+  constexpr int STAGED_BYTES = STAGED ? CFG::NW * SP_STAGED_BYTES_PER_WAVE : 0;
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64 + STAGED_BYTES + TL_EXTRA];
 
   const int tid  = threadIdx.x;
   // (measurement build: stamps go to the 64 scratch bytes behind the stages; slot 0 doubles as the fused vote word,
@@ -475,6 +487,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
   SQ_LOAD_ITEM(0, 0);
   SQ_LOAD_ITEM(1, 0);
+  HGEMM_TL_STAMP(smem + CFG::LDS_BYTES + 64 + STAGED_BYTES, 0, tid);   // arguments read, coordinates and offsets computed
   // prologue: A(0), B(0) -> stage 0, A(1), B(1) -> stage 1
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -488,8 +501,10 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int n = 0; n < FM * FN * NQ; ++n) sp_zero_acc(n);
+  HGEMM_TL_STAMP(smem + CFG::LDS_BYTES + 64 + STAGED_BYTES, 1, tid);   // both tiles issued, accumulators cleared
   wait_vmcnt<CFG::NJA + CFG::NJB>();   // tile 0 landed (tile 1 may fly)
   __builtin_amdgcn_s_barrier();
+  HGEMM_TL_STAMP(smem + CFG::LDS_BYTES + 64 + STAGED_BYTES, 2, tid);   // tile 0 landed for every wave
 
   // fragment sets: X = A first half, Y / Z = A second half (alternating), U = B first half, V = B second half
   f16x8 fX[NFA], fY[NFA], fZ[NFA], fU[NFB], fV[NFB];
@@ -640,6 +655,8 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
 #pragma unroll
     for (int w = 0; w < 8; ++w) tl[w] = hgemm_tl_get(smem + CFG::LDS_BYTES, w);
+#pragma unroll
+    for (int w = 0; w < 3; ++w) tl[11 + w] = hgemm_tl_get(smem + CFG::LDS_BYTES + 64 + STAGED_BYTES, w);   // 11..13: head split
     tl[8] = ((unsigned long long)xcc << 32) | hw; tl[9] = (unsigned long long)step; tl[10] = (unsigned long long)walk.count;
   }
 #endif
