@@ -72,7 +72,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // kernel.  With HGEMM_FASTDIV the host passes multipliers (GemmArgs::rd) and a division is s_mul_hi + 4 ALU ops.
 // tests/test_host_logic.py compares raster_fast with raster_ref on the host for every id of many launch shapes.
 #ifndef HGEMM_FASTDIV
-#define HGEMM_FASTDIV 0
+#define HGEMM_FASTDIV 1
 #endif
 struct FastDiv { uint32_t mul, sh1, sh2; };   // n / d = (t + ((n - t) >> sh1)) >> sh2,  t = mulhi(n, mul)
 __host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f) {
@@ -198,6 +198,36 @@ inline void set_raster_div(GemmArgs& g) {   // host: after tiles_m / tiles_n / g
   g.rd = make_raster_div(g.tiles_m, g.tiles_n, g.group_m, g.tail_tiles);
 #else
   (void)g;
+#endif
+}
+
+// Kernel-argument prefetch.  GemmArgs is passed by value: the kernel reads it from the launch's kernarg buffer with scalar
+// loads, and hipcc places those where the values are first needed -- three dependent round trips for the three 64-byte
+// lines of the struct, each a cold miss (every launch gets a fresh kernarg buffer).  Round-3 timeline: 2.6k cycles (1.6 us)
+// pass between kernel entry and the first LDS-DMA piece with or without the multiplier raster map, i.e. the arithmetic is
+// not what takes the time.  One dword of every line is requested at entry instead, all at once (ONE round trip): the
+// compiler's own loads then hit the scalar cache.  (By-value structs cannot use the CP's kernarg preload.)
+#ifndef HGEMM_KERNARG_PREFETCH
+#define HGEMM_KERNARG_PREFETCH 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void prefetch_kernargs() {
+#if defined(__HIP_DEVICE_COMPILE__) && HGEMM_KERNARG_PREFETCH
+  // one statement: the loads AND their wait (a scalar load writes its destination when it returns; the compiler would
+  // consider an unused destination free again right behind the statement and the late write would corrupt its new value)
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned d0, d1, d2, d3;
+  if constexpr (BYTES > 192)
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
+  else if constexpr (BYTES > 128)
+    asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x40\n\ts_load_dword %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2) : "s"(ka));
+  else if constexpr (BYTES > 64)
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1) : "s"(ka));
+  else
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0) : "s"(ka));
+  (void)d0; (void)d1; (void)d2; (void)d3;
 #endif
 }
 
@@ -507,6 +537,7 @@ __device__ __forceinline__ void stage_tile_tail(__amdgpu_buffer_rsrc_t rsA, __am
 
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NBUF = CFG::NBUF;
   constexpr int FM = CFG::FM, FN = CFG::FN, NW = CFG::NW, NJ = CFG::NJ;

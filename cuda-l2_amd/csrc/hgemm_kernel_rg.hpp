@@ -55,6 +55,7 @@ __device__ __forceinline__ f16x8 rg_load_chunk(const f16* p, int valid, int w) {
 // CFG = Cfg<BM, BN, WM, WN, 16, 2>.  wa / wb: piece width (halfs) of the A / Bt loads; vec_c: 8-byte C stores allowed.
 template <class CFG>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_ragged_kernel(const GemmArgs g, int wa, int wb, int vec_c) {
+  prefetch_kernargs<sizeof(GemmArgs) + 12>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, THREADS = CFG::THREADS;
   constexpr int CA = BM * 8 / THREADS, CB = BN * 8 / THREADS;   // 16-byte chunks per thread per operand

@@ -83,6 +83,7 @@ __device__ __forceinline__ void classic_epilogue(const GemmArgs& g, const TileCo
 template <class CFG, int EPI>
 // two workgroups per CU wherever the tile allows it (second argument = waves per SIMD: <= 256 registers)
 __global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) ? 2 : 1) hgemm_tn_rs_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, THREADS = CFG::THREADS;
   constexpr int RB = CFG::RB, NCH = CFG::NCH, KS = CFG::KS, CA = CFG::CA, CB = CFG::CB, BKS = CFG::BKS;

@@ -421,6 +421,7 @@ constexpr int SP_EPI_NARROW = 0, SP_EPI_WIDE = 1, SP_EPI_SLAB = 2, SP_EPI_FUSED 
 
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sp_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ, MI = CFG::MI;
   constexpr int NFA = CFG::NFA, NFB = CFG::NFB;

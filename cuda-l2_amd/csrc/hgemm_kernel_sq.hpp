@@ -430,6 +430,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
 // EPI: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB / SP_EPI_FUSED (as family "s")
 template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ, MI = CFG::MI;
   constexpr int NFA = CFG::NFA, NFB = CFG::NFB;
@@ -489,18 +490,29 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   SQ_LOAD_ITEM(1, 0);
   HGEMM_TL_STAMP(smem + CFG::LDS_BYTES + 64 + STAGED_BYTES, 0, tid);   // arguments read, coordinates and offsets computed
   // prologue: A(0), B(0) -> stage 0, A(1), B(1) -> stage 1
+  // The accumulators are cleared BETWEEN the pieces: round-3 timeline, 4096^3: the 32 pieces take ~3.7k cycles to issue
+  // (the address path accepts a cold piece every ~100 cycles; the first tile has landed 150 cycles after the last piece is
+  // out) and the 256 v_accvgpr_write another ~1k behind them -- the VALU work fits into the issue stalls.
+  constexpr int NZ = FM * FN * NQ, NPIECE = 2 * (CFG::NJA + CFG::NJB);
+  int zi = 0, pi = 0;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int p = 0; p < CFG::NJA; ++p) sq_issue_piece<CFG, 0>(rsA, voffA, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
+    for (int p = 0; p < CFG::NJA; ++p) {
+      sq_issue_piece<CFG, 0>(rsA, voffA, smem + s * CFG::STAGE_BYTES, wave, p, cur[0].kbyte);
+      for (++pi; zi < (pi * NZ) / NPIECE; ++zi) sp_zero_acc(zi);
+    }
 #pragma unroll
-    for (int p = 0; p < CFG::NJB; ++p) sq_issue_piece<CFG, 1>(rsB, voffB, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
+    for (int p = 0; p < CFG::NJB; ++p) {
+      sq_issue_piece<CFG, 1>(rsB, voffB, smem + s * CFG::STAGE_BYTES, wave, p, cur[1].kbyte);
+      for (++pi; zi < (pi * NZ) / NPIECE; ++zi) sp_zero_acc(zi);
+    }
     SQ_ADVANCE(0);
     SQ_ADVANCE(1);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int n = 0; n < FM * FN * NQ; ++n) sp_zero_acc(n);
+  for (; zi < NZ; ++zi) sp_zero_acc(zi);
   HGEMM_TL_STAMP(smem + CFG::LDS_BYTES + 64 + STAGED_BYTES, 1, tid);   // both tiles issued, accumulators cleared
   wait_vmcnt<CFG::NJA + CFG::NJB>();   // tile 0 landed (tile 1 may fly)
   __builtin_amdgcn_s_barrier();

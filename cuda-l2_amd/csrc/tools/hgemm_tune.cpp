@@ -183,6 +183,30 @@ static bool g_try_nt = false;   // tune --nt: streaming C stores for the winner,
 static int default_group(int cfg, const Shape& sh) { return hgemm_mi355x_default_group(cfg, sh.M, sh.N); }
 
 static std::vector<std::string> g_config_filter;  // --configs a,b,c: only these geometries are candidates
+// tune --cand-file F: explicit candidate plans per shape, one line per shape: "M_N_K config:splits:group config:splits:group ..."
+// (tools/make_cand_file.py writes it from earlier tuning runs: a targeted re-tune measures a handful of plans per shape
+// instead of the model's whole list)
+#include <map>
+static std::map<std::string, std::vector<Plan>> g_cand_file;
+static bool load_cand_file(const char* path) {
+  std::ifstream f(path);
+  if (!f) return false;
+  std::string line;
+  while (std::getline(f, line)) {
+    std::stringstream ss(line);
+    std::string key, tok;
+    if (!(ss >> key) || key[0] == '#') continue;
+    std::vector<Plan>& v = g_cand_file[key];
+    while (ss >> tok) {
+      const size_t a = tok.find(':'), b = tok.rfind(':');
+      if (a == std::string::npos || b == a) continue;
+      const int cfg = hgemm_mi355x_config_by_name(tok.substr(0, a).c_str());
+      if (cfg < 0) continue;   // a retired geometry
+      v.push_back({cfg, atoi(tok.substr(a + 1, b - a - 1).c_str()), atoi(tok.substr(b + 1).c_str()), 0.0});
+    }
+  }
+  return true;
+}
 static bool g_fused_too = false;               // --fused: also time the single-launch form of every split-K plan
 
 static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_cand) {
@@ -366,6 +390,15 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       hgemm_mi355x_plan(sh.M, sh.N, sh.K, &p.cfg, &p.splits, &p.group_m);
       p.model_us = p.cfg >= 0 ? hgemm_mi355x_model_us(p.cfg, p.splits, sh.M, sh.N, sh.K) : 0.0;
       cands.push_back(p);
+    } else if (!g_cand_file.empty()) {
+      auto it = g_cand_file.find(key);
+      if (it != g_cand_file.end())
+        for (Plan p : it->second) {
+          if (sh.K % hgemm_mi355x_config_k_granularity(p.cfg) != 0) continue;
+          p.model_us = hgemm_mi355x_model_us(p.cfg, p.splits & HGEMM_SPLITK_MASK, sh.M, sh.N, sh.K);
+          cands.push_back(p);
+        }
+      if (cands.empty()) cands = candidates(sh, keep_ratio, std::min(max_cand, 6));   // a shape the file does not know
     } else {
       cands = candidates(sh, keep_ratio, max_cand);
     }
@@ -726,6 +759,7 @@ int main(int argc, char** argv) {
     else if (a == "--autotune") autotune = true;
     else if (a == "--fused") g_fused_too = true;
     else if (a == "--nt") g_try_nt = true;
+    else if (a == "--cand-file") { if (!load_cand_file(next())) { fprintf(stderr, "cannot read --cand-file\n"); return 2; } }
     else if (a == "--configs") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) g_config_filter.push_back(t); }
     else if (a == "--plan-only") g_plan_only = true;
     else if (a == "--keep") keep = atof(next());
