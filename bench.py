@@ -18,7 +18,13 @@ N independent replicas (weak scaling, no collective on the data path).
 Extra objects on the JSON line:
   roofline      the workload's kernel (MFMA-bound): 2MNK / mean launch duration, measured live with HIP events that
                 ride on the dispatch packets of a sample of the timed region's launches (every 16th; on the launch
-                stream, hipExtLaunchKernel start/stop events), vs the 2.5 PFLOP/s dense fp16 MFMA peak
+                stream, hipExtLaunchKernel start/stop events), vs the 2.5 PFLOP/s dense fp16 MFMA peak.
+                In a back-to-back stream a dispatch's start event fires while its predecessor is still draining
+                (launch ramp and the end-of-kernel cache write-back overlap), so avg_launch_us slightly OVERSTATES the
+                kernel: batch x avg_launch_us exceeds ms_per_step by ~1 % (the wall-clock `value` is the safer figure).
+                `traffic` (HBM + Infinity-Cache bytes per launch) is NOT measured in this run: it is read from the
+                committed rocprofv3 PMC summary named in `traffic_source` (profiles/), collected as
+                MI355X_MICROARCH.md prescribes (separate --pmc passes, FETCH_SIZE doubled on gfx950)
   cpu_baseline  the reference's CPU oracle expression (fp32 torch.matmul on the host, rounded to fp16) timed on
                 rank 0 at N=1 over a bounded sample of the same shape
   shapes        BASELINE.json's three single-GPU shapes: device-timed TFLOP/s of ours, hipBLASLt heuristic AND
@@ -287,7 +293,7 @@ def per_shape_report(lib, probs, stream) -> dict:
         cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.hgemm_mi355x_plan(p.m, p.n, p.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
         name = lib.hgemm_mi355x_config_name(cfg.value)
-        row["plan"] = {"config": name.decode() if name else "ragged", "splits": sp.value & 0xFFFF, "fused_split_k": bool(sp.value & 0x10000),
+        row["plan"] = {"config": name.decode() if name else "ragged", "splits": sp.value & 0xFFFF, "fused_split_k": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000),
                        "group_m": gm.value}
         row["roofline"] = roofline_entry(p, row["ours_us"], measured_traffic_bytes(p.mnk))
         out[p.mnk] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in row.items()}
@@ -321,18 +327,23 @@ def cpu_baseline(workload, seconds: float = 12.0) -> dict:
             "sample": f"{passes} passes of the workload's shapes as (a.float() @ b.float()).half() on the host in {dt:.1f} s"}
 
 
-def measured_traffic_bytes(mnk: str) -> float | None:
-    """HBM bytes per launch of the shape's kernel from the committed rocprofv3 PMC summaries (profiles/), if any."""
-    for name in ("pmc_summary.json", f"r02_pmc_{mnk}.json", f"r01_pmc_{mnk}.json"):
+def measured_traffic(mnk: str) -> tuple[float | None, str | None]:
+    """(HBM bytes per launch, source file) of the shape's kernel from the committed rocprofv3 PMC summaries (profiles/),
+    newest round first; (None, None) when no summary covers the shape."""
+    for name in (f"r03_pmc_{mnk}.json", "pmc_summary.json", f"r02_pmc_{mnk}.json", f"r01_pmc_{mnk}.json"):
         f = REPO / "profiles" / name
         if f.exists():
             try:
                 d = json.loads(f.read_text())["dominant_kernel"]
                 if d.get("mnk") == mnk:
-                    return float(d["hbm_bytes_per_launch"])
+                    return float(d["hbm_bytes_per_launch"]), f"profiles/{name}"
             except Exception:
                 continue
-    return None
+    return None, None
+
+
+def measured_traffic_bytes(mnk: str) -> float | None:
+    return measured_traffic(mnk)[0]
 
 
 def main(argv=None):
@@ -407,8 +418,9 @@ def main(argv=None):
     for e0, e1 in pool:
         lib.hgemm_mi355x_event_destroy(e0)
         lib.hgemm_mi355x_event_destroy(e1)
-    roof = roofline_entry(prob, dom_us, measured_traffic_bytes(prob.mnk))
-    roof.update({"kernel": prob.mnk, "avg_launch_us": round(dom_us, 2), "median_launch_us": round(durs[len(durs) // 2], 2),
+    traffic, traffic_source = measured_traffic(prob.mnk)
+    roof = roofline_entry(prob, dom_us, traffic)
+    roof.update({"traffic_source": traffic_source, "kernel": prob.mnk, "avg_launch_us": round(dom_us, 2), "median_launch_us": round(durs[len(durs) // 2], 2),
                  "launches_timed": len(durs), "algorithmic_flops_per_launch": prob.flops, "algorithmic_bytes_per_launch": prob.bytes})
     cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     lib.hgemm_mi355x_plan(prob.m, prob.n, prob.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
@@ -422,7 +434,8 @@ def main(argv=None):
                                "call each, fp16 N(0,1) operands resident in HBM; replicas per GPU",
                    "batch": args.batch, "timed_region_s": round(elapsed, 3),
                    "accumulate": "fp32 MFMA (both modes; CDNA4 has no fp16-accumulate MFMA)",
-                   "plan": {"config": cname.decode() if cname else "ragged", "splits": sp.value & 0xFFFF, "group_m": gm.value}},
+                   "plan": {"config": cname.decode() if cname else "ragged", "splits": sp.value & 0xFFFF, "nt_store": bool(sp.value & 0x20000),
+                            "group_m": gm.value}},
         "roofline": roof,
     }
     if rank == 0:

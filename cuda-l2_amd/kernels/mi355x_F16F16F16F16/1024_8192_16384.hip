@@ -1,6 +1,6 @@
 // M=1024 N=8192 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 2, raster group 16  [tuned on MI355X: 213.3 us, 1288 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 2, raster group 32  [tuned on MI355X: 211.4 us, 1300 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 16384, "q256x256_w2x2", 2, 16)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 16384, "q256x256_w2x2", 2, 32)

@@ -1,6 +1,6 @@
 // M=128 N=8192 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x4_m16_s4, split-K 4, raster group 32  [tuned on MI355X: 40.4 us, 638 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t128x128_w2x4_m16_s4, split-K 4, raster group 4  [tuned on MI355X: 56.3 us, 458 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 12288, "t128x128_w2x4_m16_s4", 4, 32)
+HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 12288, "t128x128_w2x4_m16_s4", 4, 4)

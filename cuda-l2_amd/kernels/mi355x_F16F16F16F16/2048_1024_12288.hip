@@ -1,6 +1,6 @@
 // M=2048 N=1024 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x256_w2x2, split-K 4, raster group 8  [tuned on MI355X: 60.1 us, 858 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 4, raster group 2  [tuned on MI355X: 58.5 us, 882 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 1024, 12288, "q128x256_w2x2", 4, 8)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 1024, 12288, "q256x128_w2x2", 4, 2)

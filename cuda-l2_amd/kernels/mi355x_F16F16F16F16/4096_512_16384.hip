@@ -1,6 +1,6 @@
 // M=4096 N=512 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x256_w2x2, split-K 4, raster group 8  [tuned on MI355X: 74.1 us, 927 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 4, raster group 2  [tuned on MI355X: 76.1 us, 903 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 512, 16384, "q128x256_w2x2", 4, 8)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 512, 16384, "q256x128_w2x2", 4, 2)

@@ -1,6 +1,6 @@
 // M=512 N=512 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x2_m16_s4, split-K 8, raster group 32  [tuned on MI355X: 22.5 us, 381 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x2_m16_s4, split-K 8, raster group 8  [tuned on MI355X: 23.5 us, 366 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 512, 16384, "t64x128_w2x2_m16_s4", 8, 32)
+HGEMM_MI355X_SHAPE_ENTRY(512, 512, 16384, "t64x128_w2x2_m16_s4", 8, 8)

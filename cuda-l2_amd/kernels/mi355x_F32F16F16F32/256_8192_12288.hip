@@ -1,6 +1,6 @@
 // M=256 N=8192 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 65538, raster group 2  [tuned on MI355X: 55.6 us, 928 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x256_w2x2, split-K 4, raster group 2  [tuned on MI355X: 68.2 us, 755 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 8192, 12288, "q128x128_w2x2", 65538, 2)
+HGEMM_MI355X_SHAPE_ENTRY(256, 8192, 12288, "q128x256_w2x2", 4, 2)

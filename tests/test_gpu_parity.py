@@ -638,7 +638,7 @@ def _plan_classes():
 def test_sample_of_grid_shapes_at_their_shipped_plans(g, oracle):
     """>= 50 rows of the tuned table (every family x split-K form), both entry points, the reference rule:
     0/1 inputs ({0,0,1} beyond 8192), CPU truth, mask > 2047, difference exactly 0 (zero_one_correctness_check.py:65-92,
-    263-268).  The whole grid is covered by tests/tools/verify_plans.py -> cuda-l2_amd/tuning/r02_parity_1000.jsonl."""
+    263-268).  The whole grid runs in tests/test_gpu_grid.py (and is recorded in cuda-l2_amd/tuning/r03_parity_1000.jsonl)."""
     import ctypes
 
     L = g.lib()

@@ -76,8 +76,8 @@ def test_planner_returns_a_valid_plan(lib, mnk):
     cfg, splits, group = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.hgemm_mi355x_plan(*mnk, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert 0 <= cfg.value < lib.hgemm_mi355x_num_configs()
-    count = splits.value & 0xFFFF          # | 0x10000 = HGEMM_SPLITK_FUSED (single-launch form)
-    assert splits.value & ~0x1FFFF == 0
+    count = splits.value & 0xFFFF          # | 0x10000 = HGEMM_SPLITK_FUSED (single-launch form), | 0x20000 = HGEMM_PLAN_NT_STORE
+    assert splits.value & ~0x3FFFF == 0
     assert 1 <= count <= max(1, mnk[2] // 64) and group.value >= 1
     assert lib.hgemm_mi355x_model_us(cfg.value, count, *mnk) > 0
     info = (ctypes.c_int * 8)()
@@ -269,19 +269,19 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
     adopts plans with a passing record of tests/tools/verify_plans.py (the reference's 0/1 rule, bit-exact against
     the CPU oracle, measured on an MI355X); the records are committed and this test ties the table to them."""
     ok = set()
-    for ln in (PKG / "tuning" / "r02_candidate_parity.jsonl").read_text().splitlines():
+    for ln in (PKG / "tuning" / "r03_candidate_parity.jsonl").read_text().splitlines():
         r = json.loads(ln)
         if r["pass"] and r["bitwise_equal_unmasked"] and r["guard_bars_intact"] and r["max_diff_masked"] == 0.0:
             ok.add((r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["group_m"]))
     missing = [(m, n, k, c) for (m, n, k, c, s, g) in _tuned_rows() if (f"{m}_{n}_{k}", c, s, g) not in ok]
     assert not missing, missing[:5]
     # ... and the whole-grid run of the SHIPPED table through both entry points (2 x 1000 records, all exact)
-    recs = [json.loads(ln) for ln in (PKG / "tuning" / "r02_parity_1000.jsonl").read_text().splitlines()]
+    recs = [json.loads(ln) for ln in (PKG / "tuning" / "r03_parity_1000.jsonl").read_text().splitlines()]
     assert len(recs) == 2000 and all(r["pass"] and r["bitwise_equal_unmasked"] for r in recs)
     assert {r["run"] for r in recs} == {"fp32", "fp16"} and len({r["mnk"] for r in recs}) == 1000
-    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), g) for (m, n, k, c, s, g) in _tuned_rows()}
+    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), g) for (m, n, k, c, s, g) in _tuned_rows()}
     for r in recs:
-        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["group_m"]) in shipped, r["mnk"]
+        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["group_m"]) in shipped, r["mnk"]
 
 
 def test_analytic_model_picks_near_optimal_plans_on_the_measured_candidates(lib):
@@ -462,5 +462,5 @@ def test_planner_fuzz_every_answer_is_launchable(lib):
         assert 0 <= c.value < n_cfg, (m, n, k, c.value)
         gran = lib.hgemm_mi355x_config_k_granularity(c.value)
         assert k % gran == 0, (m, n, k, lib.hgemm_mi355x_config_name(c.value), gran)
-        assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x1FFFF) == 0 and g.value >= 1
+        assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x3FFFF) == 0 and g.value >= 1
         assert not lib.hgemm_mi355x_config_name(c.value).decode().endswith("_m32") or lib.hgemm_mi355x_config_name(c.value).decode().startswith("t")
