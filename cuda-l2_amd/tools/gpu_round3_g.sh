@@ -5,6 +5,11 @@
 # shapes with the same time boxes; (3) BASELINE config 4 (512x4096x4096 fp32, server mode) at qps 10 / 100 / 1000 with
 # >= 1000 recorded samples each.
 set -u
+# (0) chip-filling split-K factors (tools/make_fill_candidates.py) for the under-filled shapes: targeted re-tune + oracle check
+O=gpurun_out/r3g; mkdir -p $O
+timeout 600 cuda-l2_amd/bin/hgemm_tune tune --shape-file cuda-l2_amd/tuning/.fill_shapes.txt --cand-file cuda-l2_amd/tuning/r03_fill_candidates.txt --nt --baselines --out $O/fill_tune.jsonl > $O/fill_tune.log 2>&1
+echo "fill tune rc=$? lines=$(wc -l < $O/fill_tune.jsonl)"
+timeout 300 python tests/tools/verify_plans.py --plans $O/fill_tune.jsonl --top 3 --repeats 2 --out $O/fill_verify.jsonl > $O/fill_verify.log 2>&1; tail -1 $O/fill_verify.log
 S=gpurun_out/sweep_r03; mkdir -p $S
 awk 'NR % 8 == 1' cuda-l2_amd/tools/grid_shapes.txt > cuda-l2_amd/tools/.eighth.txt
 W="--warmup_seconds 0.04 --benchmark_seconds 0.15"
