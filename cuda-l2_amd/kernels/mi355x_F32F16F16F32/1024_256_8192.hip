@@ -1,6 +1,6 @@
 // M=1024 N=256 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x32_w2x1_m16_s4, split-K 4 (single launch), raster group 4  [tuned on MI355X: 18.1 us, 237 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x32_w2x1_m16_s4, split-K 6 (single launch), raster group 4  [tuned on MI355X: 17.3 us, 249 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 256, 8192, "t64x32_w2x1_m16_s4", 65540, 4)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 256, 8192, "t64x32_w2x1_m16_s4", 65542, 4)

