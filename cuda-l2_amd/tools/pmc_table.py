@@ -4,6 +4,8 @@ representative grid shape of every kernel geometry that serves at least `--min-r
   python tools/pmc_table.py shapes [--min-rows 5]          -> the shape list (one M_N_K per line, largest-flop row of
                                                              each geometry plus the BASELINE shapes)
   python tools/pmc_table.py table PASS_ROOT SHAPES.txt       -> JSON table from the passes tools/pmc_table.sh collected
+  python tools/pmc_table.py baseline TABLE.json OUT_DIR      -> OUT_DIR/r03_pmc_<M_N_K>.json of the BASELINE.json shapes
+                                                             (what bench.py's roofline.traffic reads)
 
 Collection (tools/pmc_table.sh): three rocprofv3 --pmc passes (SQ + GRBM counters, FETCH_SIZE, WRITE_SIZE -- their TCC
 slots do not fit one pass, MI355X_MICROARCH.md) of ONE process that benches every shape with its shipped plan, 3 warm-up
@@ -74,13 +76,29 @@ def groups_of(csv_path: str):
 
 def main() -> int:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("cmd", choices=["shapes", "table"])
+    ap.add_argument("cmd", choices=["shapes", "table", "baseline"])
     ap.add_argument("root", nargs="?")
     ap.add_argument("shapes", nargs="?")
     ap.add_argument("--min-rows", type=int, default=5)
     a = ap.parse_args()
     if a.cmd == "shapes":
         print("\n".join(pick_shapes(a.min_rows)))
+        return 0
+    if a.cmd == "baseline":
+        # baseline <table.json> <out dir>: one r03_pmc_<M_N_K>.json per BASELINE.json shape, the form bench.py's
+        # measured_traffic() reads (dominant_kernel.{mnk, hbm_bytes_per_launch})
+        tab = json.load(open(a.root))
+        for row in tab["rows"]:
+            if row["mnk"] not in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
+                continue
+            rec = {"source": tab["source"], "hbm_bytes": tab["hbm_bytes"], "table": "profiles/r03_pmc_table.json",
+                   "dominant_kernel": {"mnk": row["mnk"], "kernel": row["kernels"][0] if row["kernels"] else None,
+                                       "hbm_bytes_per_launch": row["hbm_bytes_per_launch"],
+                                       "algorithmic_bytes_per_launch": row["algorithmic_bytes_per_launch"],
+                                       "avg_kernel_us_profiled": row["avg_kernel_us_profiled"]},
+                   "row": row}
+            with open(f"{a.shapes}/r03_pmc_{row['mnk']}.json", "w") as f:
+                json.dump(rec, f, indent=1)
         return 0
     shapes = [s.strip() for s in open(a.shapes) if s.strip()]
     plans = {f"{r[0]}_{r[1]}_{r[2]}": r for r in table_rows()}
