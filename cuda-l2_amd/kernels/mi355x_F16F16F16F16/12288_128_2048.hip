@@ -1,6 +1,6 @@
 // M=12288 N=128 K=2048  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x2_m16_s4, split-K 1, raster group 16  [tuned on MI355X: 21.4 us, 301 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 1, raster group 8  [tuned on MI355X: 19.0 us, 338 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 128, 2048, "t64x128_w2x2_m16_s4", 1, 16)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 128, 2048, "t64x128_w2x4_m16_s4", 1, 8)

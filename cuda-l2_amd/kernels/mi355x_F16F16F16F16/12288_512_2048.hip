@@ -1,5 +1,5 @@
 // M=12288 N=512 K=2048  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x256_w2x2, split-K 1, non-temporal C stores, raster group 1  [tuned on MI355X: 30.6 us, 842 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x256_w2x2, split-K 1, non-temporal C stores, raster group 1  [tuned on MI355X: 31.5 us, 817 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

@@ -1,6 +1,6 @@
 // M=12288 N=64 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 1, raster group 8  [tuned on MI355X: 29.5 us, 218 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r96x64_k128, split-K 2 (single launch), raster group 4  [tuned on MI355X: 25.2 us, 255 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 64, 4096, "t64x64_w2x2_m16_s4", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 64, 4096, "r96x64_k128", 65538, 4)

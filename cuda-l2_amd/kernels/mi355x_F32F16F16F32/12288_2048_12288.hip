@@ -1,6 +1,6 @@
 // M=12288 N=2048 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 2, raster group 1  [tuned on MI355X: 484.1 us, 1278 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q192x256_w2x2, split-K 1, raster group 8  [tuned on MI355X: 465.5 us, 1329 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 2048, 12288, "q256x256_w2x2", 2, 1)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 2048, 12288, "q192x256_w2x2", 1, 8)

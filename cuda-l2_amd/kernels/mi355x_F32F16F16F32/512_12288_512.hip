@@ -1,6 +1,6 @@
 // M=512 N=12288 K=512  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w2x2_m16_s2, split-K 1, raster group 8  [tuned on MI355X: 14.8 us, 436 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 1, non-temporal C stores, raster group 2  [tuned on MI355X: 11.1 us, 579 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 12288, 512, "t128x64_w2x2_m16_s2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(512, 12288, 512, "q256x128_w2x2", 131073, 2)

@@ -1,6 +1,6 @@
 // M=512 N=4096 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 2, raster group 8  [tuned on MI355X: 31.8 us, 540 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t128x64_w4x2_m16_s4, split-K 1, raster group 4  [tuned on MI355X: 29.8 us, 576 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 4096, "q128x128_w2x2", 2, 8)
+HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 4096, "t128x64_w4x2_m16_s4", 1, 4)

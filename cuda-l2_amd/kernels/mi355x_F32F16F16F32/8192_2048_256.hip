@@ -1,6 +1,6 @@
 // M=8192 N=2048 K=256  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t256x256_w2x4_m16_s2, split-K 1, raster group 1  [tuned on MI355X: 18.0 us, 477 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X: 15.8 us, 543 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 2048, 256, "t256x256_w2x4_m16_s2", 1, 1)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 2048, 256, "q256x256_w2x2", 131073, 8)

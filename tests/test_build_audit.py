@@ -92,8 +92,13 @@ def test_sp_k_loops_are_mfma_streams_with_scalar_dma_descriptors(sp_functions):
         n16 = len(re.findall(r"\bv_mfma_f32_16x16x32_f16", hot))
         n32 = len(re.findall(r"\bv_mfma_f32_32x32x16_f16", hot))
         assert (n16 == 0) != (n32 == 0), f"{name}: one MFMA shape per kernel ({n16} / {n32})"
-        # one K-step = BM*BN*64*2 flop / 4 waves: a multiple of 64 16x16x32 MFMAs or of 32 32x32x16 MFMAs
-        assert (n16 > 0 and n16 % 64 == 0) or (n32 > 0 and n32 % 32 == 0), f"{name}: {n16} / {n32} MFMAs in the hot loop"
+        # a trip is a whole number of K-steps (K = 64) of the wave tile: (BM / WM) x (BN / WN) x 64 per K-step = FM * FN * 2
+        # 16x16x32 MFMAs or FM * FN * 4 32x32x16 MFMAs (geometry from the mangled CfgSP / CfgSQ template arguments)
+        bm, bn, wm, wn = map(int, re.search(r"Cfg\w+?ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name).groups())
+        mi = 16 if n16 else 32
+        per_step = (bm // wm // mi) * (bn // wn // mi) * (2 if n16 else 4)
+        n = n16 or n32
+        assert n >= per_step and n % per_step == 0, f"{name}: {n16} / {n32} MFMAs in the hot loop, {per_step} per K-step"
         body = list(_outside_asm(hot.splitlines()))
         # LDS-DMA with a divergent descriptor is wrapped in a waterfall loop (readfirstlane + exec masking)
         assert not [ln for ln in body if re.search(r"v_readfirstlane|s_and_saveexec|s_cbranch_execn?z", ln)], name

@@ -587,6 +587,14 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("t64x64_w2x2_m16_s4", 16 | 0x10000, (192, 320, 8192)),  # classic 4-deep ring + single-launch split-K
         ("t128x128_w2x2_m16_s3", 1, (2048, 2048, 1024)),   # classic 3-deep ring
         ("t256x256_w2x4_m16_s2", 1, (2048, 2048, 1024)),   # classic 8-wave double buffer
+        ("t128x64_w4x2_m16_s4", 1, (1000, 1096, 2048)),    # 8-wave 128x64 tile, 4-deep ring, ragged edges
+        ("t64x128_w2x4_m16_s3", 2 | 0x10000, (512, 4096, 4160)),  # 8-wave 64x128 tile, 3-deep ring, two workgroups per CU, single-launch split-K
+        ("q192x256_w2x2", 1, (6144, 4608, 576)),           # 192-row persistent tile (staged epilogue), several items, odd K-step count (9)
+        ("q192x256_w2x2", 1, (1000, 520, 192)),            # ... three K-steps, ragged edges (the shape the withdrawn 192x192 member failed)
+        ("q256x192_w2x2", 3, (1100, 1000, 4096)),          # 192-column persistent tile (row epilogue), two-pass split-K, ragged edges
+        ("q256x192_w2x2", 2 | 0x10000, (1024, 1536, 4160)),# ... single-launch split-K, odd slice lengths
+        ("r96x128_k128", 2 | 0x10000, (1536, 128, 4096)),  # 96-row streaming tile
+        ("r64x96_k128", 1, (100, 1056, 2048)),             # 96-column streaming tile, ragged M
     ]
     for cfg, splits, (m, n, k) in cases:
         cid = names.index(cfg)

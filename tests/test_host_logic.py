@@ -425,6 +425,11 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
                     (48, 4096, 64), (3000, 4096, 128)]:
         cfg, splits, group = plan(m, n, k)
         corners = {plan(a, b, c)[0] for a in bracket(m) for b in bracket(n) for c in bracket(k)}
+        # (round 3: a dimension that is a multiple of 192 also admits the 192-wide persistent tile of that side)
+        if m % 192 == 0:
+            corners.add(lib.hgemm_mi355x_config_by_name(b"q192x256_w2x2"))
+        if n % 192 == 0:
+            corners.add(lib.hgemm_mi355x_config_by_name(b"q256x192_w2x2"))
         assert cfg in corners, (m, n, k, lib.hgemm_mi355x_config_name(cfg))
         assert k % lib.hgemm_mi355x_config_k_granularity(cfg) == 0
         assert 1 <= (splits & 0xFFFF) <= max(1, k // 64) and group >= 1
@@ -441,6 +446,8 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
     first = [plan(*s) for s in shapes]
     assert [plan(*s) for s in shapes] == first
     assert plan(4096, 4096, 4096)[0] == lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
+    # 3072 = 12 x 256 = 16 x 192: 144 tiles of 256 x 256 leave 112 CUs idle, 192 tiles of 192 x 256 leave 64
+    assert plan(3072, 3072, 3072)[0] == lib.hgemm_mi355x_config_by_name(b"q192x256_w2x2")
 
 
 def test_planner_fuzz_every_answer_is_launchable(lib):
