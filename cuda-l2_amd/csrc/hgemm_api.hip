@@ -197,8 +197,12 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   // Round 3 (tuning/r03_late_tune_mi355x.jsonl, 706 candidates): the 8-wave 128x64 / 64x128 members of the classic family run at
   // 0.78 of this model's time where their 4-wave counterparts run at 1.07 -- two waves per SIMD hide the LDS-DMA issue stalls
   // the per-step latency term charges; the 192-wide q members sit on the family's common ratio (1.41 vs 1.39-1.42).
-  const bool w8_mid = family == 't' && nw == 8 && e.bm * e.bn <= 128 * 64;
-  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (is_q128 ? 1.0 : family == 's' ? 1.47 : w8_mid ? 1.4 : 1.0);
+  const bool w8_mid = family == 't' && nw == 8 && e.bm * e.bn <= 128 * 64 && wgs <= 2L * kCUs;   // (the fitted domain: <= 512 workgroups)
+  // a 192-wide q tile costs 0.87 of a 256 x 256 one for 0.75 of its flops (12288 x 1024 x 16384: 396 -> 342 us with as many
+  // rounds; 1024 x 12288 x 12288: 256 -> 225): fewer flops per LDS-DMA piece and per fragment read, one of them without the staged
+  // epilogue -- without this term the off-grid ranking takes them whenever they save a fraction of a round
+  const bool q192 = is_q && (e.bm == 192 || e.bn == 192);
+  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (is_q128 ? 1.0 : family == 's' ? (q192 ? 1.47 / 1.16 : 1.47) : w8_mid ? 1.4 : 1.0);
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
   // per-K-step latency floor: barrier + LDS-DMA round trip (double-buffered rings expose all of it)
   const double step_lat = family == 's' ? 0.40 : (e.nbuf >= 3 ? 0.33 : 0.74);
@@ -278,6 +282,10 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     if ((e.bm > M * 2 && e.bm > 32) || (e.bn > N * 2 && e.bn > 32)) continue;   // mostly padding
     const int ksteps = std::max(1, K / e.kgran);
     const int s = std::max(1, std::min(p->splits & HGEMM_SPLITK_MASK, ksteps));
+    // the 8-wave mid tiles were tuned (and the model fitted) for at most two workgroups per CU: beyond that the larger tiles of
+    // another corner win (1332 x 3108 x 4440: 525 tiles of 64 x 128 measured 101 us against 82 us for the 256 x 256 corner plan)
+    if (e.name[0] == 't' && e.wm * e.wn == 8 && e.bm * e.bn <= 128 * 64 &&
+        (long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) * s > 2L * kCUs) continue;
     const double t = model_us(e, M, N, K, s);
     if (t < best) {
       best = t; found = true;
@@ -299,6 +307,8 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       const int c = hgemm_mi355x_config_by_name(name);
       if (c < 0) continue;
       const KernelEntry& e = g_kernel_table[c];
+      // (only where the 192-wide tiles fill at least half the chip: 1968 x 576 has 24 of them and measured 0.72x of its corner plan)
+      if ((long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) < kCUs / 2) continue;
       for (int s : {1, best_s}) {
         if (s > std::max(1, K / e.kgran)) continue;
         const double t = model_us(e, M, N, K, s);

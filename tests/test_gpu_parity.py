@@ -635,11 +635,15 @@ def _plan_classes():
             continue
         key = (cfg[0] + ("32" if cfg.endswith("m32") else ""), "1" if (sp & 0xFFFF) == 1 else ("fused" if sp & 0x10000 else "2pass"))
         buckets.setdefault(key, []).append(r)
-    picked = []
+    picked, rest = [], []
     per = max(4, 60 // max(1, len(buckets)))
     for key, rs in sorted(buckets.items()):
         rs = sorted(rs, key=lambda r: (r[0] * 7919 + r[1] * 104729 + r[2]) % 1009)   # deterministic spread
         picked += rs[:per]
+        rest += rs[per:]
+    # small buckets (a family with three plans left) must not shrink the sample: top up from the others, spread the same way
+    rest = sorted(rest, key=lambda r: (r[0] * 7919 + r[1] * 104729 + r[2]) % 1009)
+    picked += rest[:max(0, 56 - len(picked))]
     return picked
 
 
