@@ -49,7 +49,8 @@ typedef enum {
  * selects the compute type exactly as the reference's cublas/fp16 vs cublas/fp32 trees do. */
 typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
 
-/* Special config ids of hgemm_mi355x_launch / hgemm_mi355x_plan (ids >= 0 index the geometry table). */
+/* Special config ids of hgemm_mi355x_launch / hgemm_mi355x_plan (ids >= 0 index the geometry table of THIS library build:
+ * resolve a geometry by name with hgemm_mi355x_config_by_name, ids shift when a build adds members). */
 #define HGEMM_CONFIG_GENERIC (-1) /* one-output-per-thread reference kernel; reads b (row-major)        */
 #define HGEMM_CONFIG_RAGGED  (-2) /* register-staged MFMA kernel for any M,N,K / alignment; reads b_col_major */
 
