@@ -266,6 +266,16 @@ __device__ __forceinline__ void sq_piece_load(__amdgpu_buffer_rsrc_t rs, const u
   static_assert(HGEMM_DMA_AUX == 0, "cache-policy experiments use the builtin form");
   asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[q]), "s"(rs), "s"(kbyte + sub * ROW_BYTES) : "memory");
 }
+// every register of the three fragment sets the next MFMAs read is an operand of one asm statement: whatever copies the
+// compiler owes them are done in front of it, and its s_nop covers the VALU -> MFMA-source wait states
+template <int NA, int NB>
+__device__ __forceinline__ void sq_settle(f16x8 (&x)[NA], f16x8 (&y)[NA], f16x8 (&u)[NB]) {
+#pragma unroll
+  for (int r = 0; r < NA; ++r) asm volatile("" : "+v"(x[r]), "+v"(y[r]));
+#pragma unroll
+  for (int r = 0; r < NB; ++r) asm volatile("" : "+v"(u[r]));
+  asm volatile("s_nop 1");
+}
 constexpr int kWaitLgkm0 = 0xC07F;   // s_waitcnt lgkmcnt(0) as the builtin's immediate (vmcnt 63, expcnt 7 = no wait)
 
 // One interval.  PHASE 0 = A(t): MFMAs af x bf; leading reads -> lead (B fragments of the second half of tile t);
@@ -558,9 +568,18 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       SQ_K_STEP(fZ, fY, SQ_ADVANCE(0), SQ_ADVANCE(1));
     }
     if (t < nk) {   // odd K-step count: one more step, then put the next tile's slice-1 fragments back into Y
+      // This block is a control-flow merge (entered from the prologue, the hot loop or the tail loop) and ends with a register
+      // copy: hipcc may move fragment registers around it with VALU instructions.  The MFMAs are asm statements, so its hazard
+      // recognizer does not see them: an MFMA that reads a VGPR within two wait states of a VALU write gets the OLD value
+      // (found with a 192 x 192 member, DESIGN.md section 4.8: the compiler moved A fragment 5 from v[2:5] to v[0:3] right in
+      // front of its first MFMA -- one output tile wrong whenever the K-step count was odd).  sq_settle makes every fragment
+      // set live in its final registers here and spends the two wait states; tests/test_build_audit.py checks the condition on
+      // every MFMA of every persistent kernel.
+      sq_settle(fX, fY, fU);
       SQ_K_STEP(fY, fZ, SQ_ADVANCE(0), SQ_ADVANCE(1));
 #pragma unroll
       for (int r = 0; r < NFA; ++r) fY[r] = fZ[r];
+      sq_settle(fX, fY, fU);
     }
     // ---- epilogue of this work item (as family "s"): unit by unit (MI = 16: one fragment row, MI = 32: one tile) ---
     HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 4, tid);

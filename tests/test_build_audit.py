@@ -142,3 +142,66 @@ def test_m0_writes_and_lds_dma_loads_alternate_in_the_k_loops(sp_functions):
                     assert events[i + 1] == "mfma", f"{name}: LDS-DMA right behind its M0 write"
             checked += 1
     assert checked >= 6
+
+
+def _vgprs(tok: str) -> set:
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def valu_to_mfma_source_hazards(lines):
+    """(VALU line, MFMA line) pairs where an MFMA reads a VGPR as A / B operand fewer than two wait states behind a VALU write of
+    it.  hipcc's hazard recognizer pads its own MFMAs for this; the persistent families write theirs as asm statements, which
+    it does not see -- the MFMA would read the OLD register value.  (ds_read results are ordered by lgkmcnt, not by wait
+    states, and are not VALU writes.)"""
+    recent, bad = [], []          # recent: (registers written, wait states since, text)
+    for ln in lines:
+        code = ln.split(";")[0].strip()
+        if not code or code.endswith(":") or code.startswith((".", "#")):
+            continue
+        ops = code.replace(",", " ").split()
+        mn = ops[0]
+        if mn.startswith("v_mfma"):
+            src = set()
+            for tok in ops[2:4]:
+                src |= _vgprs(tok)
+            bad += [(txt, code) for (w, age, txt) in recent if age < 2 and w & src]
+            recent = [(w, age + 1, t) for (w, age, t) in recent if age + 1 < 2]
+            continue
+        step = int(ops[1]) + 1 if mn == "s_nop" else 1
+        recent = [(w, age + step, t) for (w, age, t) in recent if age + step < 2]
+        if mn.startswith("v_") and not mn.startswith(("v_cmp", "v_accvgpr_write")) and len(ops) > 1:
+            w = _vgprs(ops[1])
+            if w:
+                recent.append((w, 0, code))
+    return bad
+
+
+def test_no_valu_write_sits_within_two_wait_states_of_an_asm_mfma_that_reads_it(sp_functions):
+    """Round 3: a 192 x 192 member of family q produced one wrong output tile whenever the K-step count was odd -- hipcc had
+    moved an A fragment from v[2:5] to v[0:3] with four v_perm_b32 directly in front of its first MFMA (a control-flow merge
+    in front of the odd K-step), and an asm MFMA gets no hazard padding.  The shipped 192 x 256 member had the same pattern in
+    its narrow-epilogue variant.  sq_settle() now pins the fragment sets and spends the wait states at that merge; this test
+    keeps EVERY MFMA of every persistent kernel clear of the condition, whatever a future compiler does with the copies."""
+    funcs, _ = sp_functions
+    total = 0
+    for name, lines in funcs.items():
+        bad = valu_to_mfma_source_hazards(lines)
+        assert not bad, f"{name}: {len(bad)} MFMA source hazards, first: {bad[0]}"
+        total += sum(1 for ln in lines if ln.split(";")[0].strip().startswith("v_mfma"))
+    assert total > 5000      # the audit really saw the MFMA streams
+
+
+def test_the_hazard_audit_catches_the_pattern():
+    stream = ["v_perm_b32 v2, v123, v4, s68", "v_perm_b32 v3, v122, v5, s68",
+              "v_mfma_f32_16x16x32_f16 a[120:123], v[74:77], v[0:3], a[120:123]"]
+    assert len(valu_to_mfma_source_hazards(stream)) == 2
+    assert not valu_to_mfma_source_hazards(stream[:2] + ["s_nop 1"] + stream[2:])
+    assert not valu_to_mfma_source_hazards(["ds_read_b128 v[0:3], v9"] + stream[2:])          # LDS results: lgkmcnt's business
+    assert len(valu_to_mfma_source_hazards([stream[1], stream[2]])) == 1                      # no wait state
+    assert len(valu_to_mfma_source_hazards([stream[1], "s_nop 0", stream[2]])) == 1           # one wait state: still too close
+    assert len(valu_to_mfma_source_hazards([stream[1], "s_add_u32 m0, m0, 0x1000", stream[2]])) == 1
+    assert not valu_to_mfma_source_hazards([stream[1], "s_add_u32 m0, m0, 0x1000", "s_nop 0", stream[2]])   # two

@@ -591,6 +591,9 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("t64x128_w2x4_m16_s3", 2 | 0x10000, (512, 4096, 4160)),  # 8-wave 64x128 tile, 3-deep ring, two workgroups per CU, single-launch split-K
         ("q192x256_w2x2", 1, (6144, 4608, 576)),           # 192-row persistent tile (staged epilogue), several items, odd K-step count (9)
         ("q192x256_w2x2", 1, (1000, 520, 192)),            # ... three K-steps, ragged edges (the shape the withdrawn 192x192 member failed)
+        ("q192x256_w2x2", 1, (1000, 516, 192)),            # ... NARROW epilogue (N % 8 = 4) at an odd K-step count: the variant that carried the
+                                                           #     VALU -> asm-MFMA source hazard (tests/test_build_audit.py)
+        ("q256x192_w2x2", 1, (584, 1004, 448)),            # ... the sibling, narrow epilogue, seven K-steps
         ("q256x192_w2x2", 3, (1100, 1000, 4096)),          # 192-column persistent tile (row epilogue), two-pass split-K, ragged edges
         ("q256x192_w2x2", 2 | 0x10000, (1024, 1536, 4160)),# ... single-launch split-K, odd slice lengths
         ("r96x128_k128", 2 | 0x10000, (1536, 128, 4096)),  # 96-row streaming tile
