@@ -144,12 +144,14 @@ def test_m0_writes_and_lds_dma_loads_alternate_in_the_k_loops(sp_functions):
     assert checked >= 6
 
 
-def _vgprs(tok: str) -> set:
-    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+def _vgprs(tok: str, bank: str = "v") -> set:
+    """register numbers of a v / a operand (`a` registers are offset by 1000 so both banks share one set)"""
+    base = 0 if bank == "v" else 1000
+    m = re.match(bank + r"\[(0x[0-9a-f]+|\d+):(0x[0-9a-f]+|\d+)\]$", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"v(\d+)$", tok)
-    return {int(m.group(1))} if m else set()
+        return set(range(base + int(m.group(1), 0), base + int(m.group(2), 0) + 1))
+    m = re.match(bank + r"(\d+)$", tok)
+    return {base + int(m.group(1))} if m else set()
 
 
 def valu_to_mfma_source_hazards(lines):
@@ -168,13 +170,15 @@ def valu_to_mfma_source_hazards(lines):
             src = set()
             for tok in ops[2:4]:
                 src |= _vgprs(tok)
+            if len(ops) > 4:
+                src |= _vgprs(ops[4], "a")        # the accumulator input: v_accvgpr_write (the clears) is a VALU write, too
             bad += [(txt, code) for (w, age, txt) in recent if age < 2 and w & src]
             recent = [(w, age + 1, t) for (w, age, t) in recent if age + 1 < 2]
             continue
         step = int(ops[1]) + 1 if mn == "s_nop" else 1
         recent = [(w, age + step, t) for (w, age, t) in recent if age + step < 2]
-        if mn.startswith("v_") and not mn.startswith(("v_cmp", "v_accvgpr_write")) and len(ops) > 1:
-            w = _vgprs(ops[1])
+        if mn.startswith("v_") and not mn.startswith("v_cmp") and len(ops) > 1:
+            w = _vgprs(ops[1]) | _vgprs(ops[1], "a")
             if w:
                 recent.append((w, 0, code))
     return bad
@@ -205,3 +209,5 @@ def test_the_hazard_audit_catches_the_pattern():
     assert len(valu_to_mfma_source_hazards([stream[1], "s_nop 0", stream[2]])) == 1           # one wait state: still too close
     assert len(valu_to_mfma_source_hazards([stream[1], "s_add_u32 m0, m0, 0x1000", stream[2]])) == 1
     assert not valu_to_mfma_source_hazards([stream[1], "s_add_u32 m0, m0, 0x1000", "s_nop 0", stream[2]])   # two
+    assert len(valu_to_mfma_source_hazards(["v_accvgpr_write_b32 a121, 0", stream[2]])) == 1  # a cleared accumulator read as SrcC
+    assert not valu_to_mfma_source_hazards(["v_accvgpr_write_b32 a124, 0", stream[2]])
