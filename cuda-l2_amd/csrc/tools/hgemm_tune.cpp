@@ -183,6 +183,7 @@ static double stream_us(F&& launch, std::vector<Buffers>& sets, double seconds, 
 // in one and 10 % better in the other should win (16384^2 x 128: 256x128 tiles with streaming C stores 158 / 133 us against
 // 157 / 148 for 128x128 tiles).  Candidates slower than 1.25x the best isolated time are dropped unmeasured.
 static bool g_rank_both = false;
+static bool g_stream_report = false;   // tune --plan-only --baselines --stream
 static bool g_try_nt = false;   // tune --nt: streaming C stores for the winner, judged back to back (HGEMM_PLAN_NT_STORE)
 
 static int default_group(int cfg, const Shape& sh) { return hgemm_mi355x_default_group(cfg, sh.M, sh.N); }
@@ -488,6 +489,17 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       lt_nn = time_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
       lt_tn = time_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
     }
+    // tune --plan-only --baselines --stream: the same comparison back to back (what a model runs: launches queue behind each
+    // other, the end-of-kernel release and the clocks of a busy device are part of the figure), short boxes
+    double st_ours = -1, st_lt_nn = -1, st_lt_tn = -1;
+    if (g_plan_only && baselines && g_stream_report) {
+      const double box = flops > 1.5e12 ? 0.012 : 0.008;
+      const Plan p = res[0].p;
+      st_ours = stream_us([&](Buffers& s) { return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr); },
+                          sets, box, e0, e1, res[0].us);
+      st_lt_tn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, lt_tn);
+      st_lt_nn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, lt_nn);
+    }
     double at_nn = -1, at_tn = -1;
     int at_cand_nn = 0, at_cand_tn = 0;
     if (baselines && autotune) {
@@ -515,6 +527,8 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       fprintf(out, ", \"hipblaslt_auto_nn_us\": %.3f, \"hipblaslt_auto_tn_us\": %.3f, \"hipblaslt_auto_candidates\": [%d, %d]", at_nn, at_tn,
               at_cand_nn, at_cand_tn);
     if (nt_us > 0) fprintf(out, ", \"stream_plain_us\": %.3f, \"stream_nt_us\": %.3f", nt_plain_us, nt_us);
+    if (st_ours > 0)
+      fprintf(out, ", \"stream_us\": %.3f, \"hipblaslt_heur_tn_stream_us\": %.3f, \"hipblaslt_heur_nn_stream_us\": %.3f", st_ours, st_lt_tn, st_lt_nn);
     fprintf(out, ", \"candidates\": [");
     for (size_t i = 0; i < res.size(); ++i)
     {
@@ -788,6 +802,7 @@ int main(int argc, char** argv) {
     else if (a == "--fused") g_fused_too = true;
     else if (a == "--nt") g_try_nt = true;
     else if (a == "--rank") g_rank_both = std::string(next()) == "both";
+    else if (a == "--stream") g_stream_report = true;
     else if (a == "--cand-file") { if (!load_cand_file(next())) { fprintf(stderr, "cannot read --cand-file\n"); return 2; } }
     else if (a == "--configs") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) g_config_filter.push_back(t); }
     else if (a == "--plan-only") g_plan_only = true;

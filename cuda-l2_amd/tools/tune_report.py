@@ -43,7 +43,27 @@ def main(path, show=12):
     for x in rows:
         buckets[int(math.log10(x["flops"]))].append(x["sp_lt"])
     out["by_log10_flops"] = {b: {"n": len(v), "geomean": round(gm(v), 3), "min": round(min(v), 2), "max": round(max(v), 2)} for b, v in sorted(buckets.items())}
+    # back-to-back columns (hgemm_tune tune --plan-only --baselines --stream): the same comparison on the device clock of a
+    # busy queue
+    st = [(r, min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) / r["stream_us"]) for r in recs if r.get("stream_us", -1) > 0]
+    if st:
+        sb = collections.defaultdict(list)
+        for r, sp in st:
+            m, n, k = map(int, r["mnk"].split("_"))
+            sb[int(math.log10(2.0 * m * n * k))].append(sp)
+        fl = lambda r: 2.0 * math.prod(map(int, r["mnk"].split("_")))
+        out["back_to_back"] = {"shapes": len(st), "geomean_speedup_vs_hipblaslt_heuristic_max": gm(sp for _, sp in st),
+                               "fraction_faster": sum(sp > 1 for _, sp in st) / len(st),
+                               "aggregate_tflops_ours": sum(fl(r) for r, _ in st) / sum(r["stream_us"] for r, _ in st) * 1e-6,
+                               "aggregate_tflops_hipblaslt_max": sum(fl(r) for r, _ in st) /
+                               sum(min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) for r, _ in st) * 1e-6,
+                               "by_log10_flops": {b: {"n": len(v), "geomean": round(gm(v), 3), "min": round(min(v), 2), "max": round(max(v), 2)}
+                                                  for b, v in sorted(sb.items())}}
     print(json.dumps(out, indent=1))
+    if st:
+        for r, sp in sorted(st, key=lambda t: t[1])[:show]:
+            print("  worst back to back %-20s ours %9.1f us (%s)  hipblaslt %9.1f us  speedup %.2f" % (
+                r["mnk"], r["stream_us"], r["best"]["config"], min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]), sp))
     for x in sorted(rows, key=lambda x: x["sp_lt"])[:show]:
         print("  worst %-20s ours %9.1f us (%s s=%d g=%d)  hipblaslt %9.1f us  speedup %.2f" % (
             x["mnk"], x["ours"], x["best"]["config"], x["best"]["splits"], x["best"]["group_m"], x["lt"], x["sp_lt"]))
