@@ -314,7 +314,7 @@ __device__ __forceinline__ void sp_store_tile32(const GemmArgs& g, int m, int nb
 #endif  // __HIP_DEVICE_COMPILE__
 
 // ---- LDS-staged fp16 epilogue (round 3) -----------------------------------------------------------------------------
-// Timeline of the round-2 epilogue (tools/gpu_round3_a.sh): ~8.3-9k cycles per 256x256 tile wherever it runs (alone at the
+// Timeline of the round-2 epilogue (tools/lab/gpu_round3_a.sh): ~8.3-9k cycles per 256x256 tile wherever it runs (alone at the
 // end of a single-round grid or between the K loops of a persistent walk), i.e. ~16 B/clk/CU: it is bound by the store
 // instruction, not by bandwidth.  In the MFMA layout a lane holds 4 (8 after the lane swap) consecutive N of ONE row, so a
 // store instruction touches 16 rows x 64 B: sixteen half cache lines.  Here every wave turns its rows around in a private

@@ -57,7 +57,7 @@
                               // E = NJ - D in the pre-sync window of the NEXT interval, between its leading fragment reads.
                               // 0: round-2 plan (all pieces in the ~2/3 of an interval behind the sync point, one every 4 slots
                               // from each of the four waves at once).  Why: round-3 timeline ablation -- the pieces cost 180 of
-                              // the 214 cycles a K-step spends beyond its 2048 MFMA cycles (tools/gpu_round3_a.sh):
+                              // the 214 cycles a K-step spends beyond its 2048 MFMA cycles (tools/lab/gpu_round3_a.sh):
                               // the CU's one address path takes ~20 cycles per piece, four waves x one piece per 64 cycles
                               // saturates it behind every sync point while it idles in front of the next one.
 #endif
