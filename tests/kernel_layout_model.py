@@ -242,6 +242,47 @@ def hybrid_partition(tiles: int, ksteps: int, G: int):
     return tiles - tail, tail, S, per
 
 
+def streamk_partition(tiles: int, ksteps: int, G: int, min_steps: int = 4):
+    """Design model of the stream-K schedule planned for round 4 (what every hipBLASLt kernel on
+    this chip runs).  The tiles x ksteps K-steps of a GEMM form one sequence, tile-major; workgroup w of G takes the contiguous
+    run [start(w), start(w + 1)), start(w) = w * total // G, with a run boundary that falls within `min_steps` of a tile
+    boundary snapped onto it (a segment shorter than the pipeline prologue costs more than the imbalance it removes).
+    -> list over workgroups of segments (tile, k0, k1, slot): slot = 0 when the segment opens the workgroup's run, 1 otherwise,
+    None for a segment that covers its whole tile (stored directly, no slab).  A workgroup has at most two partial segments
+    (its first and its last), so 2 * G compact slabs suffice; the parts of a tile are consecutive workgroups in K order, the
+    one that draws the last ticket of the tile's arrival counter adds the slabs in workgroup order (deterministic, like the
+    single-launch split-K of today, whose (split, tile) items are the special case of equal parts)."""
+    total = tiles * ksteps
+    # no more workgroups than runs of min_steps; a tile shorter than two prologues is never cut (plain data-parallel walk)
+    ge = max(1, min(G, total // min_steps if ksteps >= 2 * min_steps else tiles))
+    starts = []
+    for w in range(G + 1):
+        x = min(w, ge) * total // ge
+        r = x % ksteps
+        if ksteps < 2 * min_steps:
+            x -= r if r * 2 < ksteps else r - ksteps
+        elif 0 < r < min_steps:
+            x -= r
+        elif ksteps - min_steps < r < ksteps:
+            x += ksteps - r
+        starts.append(min(x, total))
+    for w in range(1, G + 1):                       # snapping must keep the starts monotonic
+        starts[w] = max(starts[w], starts[w - 1])
+    out = []
+    for w in range(G):
+        a, b = starts[w], starts[w + 1]
+        segs = []
+        x = a
+        while x < b:
+            tile, k0 = divmod(x, ksteps)
+            k1 = min(ksteps, k0 + (b - x))
+            whole = k0 == 0 and k1 == ksteps
+            segs.append((tile, k0, k1, None if whole else (0 if x == a else 1)))
+            x += k1 - k0
+        out.append(segs)
+    return out
+
+
 def tail_item(bid: int, tail_first: int, tail_tiles: int, per: int, ksteps: int):
     """Tail-pass item id -> (tile id, first K-step, number of K-steps), as map_logical() does."""
     split, t = divmod(bid, tail_tiles)

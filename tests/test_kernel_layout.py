@@ -272,3 +272,40 @@ def test_staged_epilogue_turns_mfma_tiles_into_full_rows():
     assert len(seen) == 16 * 64 == len(out)
     assert rconf == 0
     assert wconf <= 4 * 4          # four ds_write_b64, four lane groups each, one extra cycle (rows r and r + 8) at most
+
+
+@pytest.mark.parametrize("tiles,ksteps,G", [(144, 48, 256), (192, 128, 256), (96, 128, 256), (688, 64, 256), (2304, 192, 256), (18, 3, 256),
+                                            (257, 64, 256), (255, 7, 256), (1, 256, 256), (576, 96, 256), (300, 5, 256)])
+def test_stream_k_partition_design_covers_every_k_step_once_with_two_slabs_per_workgroup(tiles, ksteps, G):
+    """Round-4 design model (kernel_layout_model.streamk_partition): the invariants the device code will rely on."""
+    part = klm.streamk_partition(tiles, ksteps, G)
+    assert len(part) == G
+    covered = {}
+    slabs = set()
+    for w, segs in enumerate(part):
+        partial = [sg for sg in segs if sg[3] is not None]
+        assert len(partial) <= 2 and len({sg[3] for sg in partial}) == len(partial)          # one slab per slot
+        assert all(sg[3] is None for sg in segs[1:-1])                                         # only the run's ends are partial
+        assert [sg[0] for sg in segs] == sorted({sg[0] for sg in segs})                        # one segment per tile, in order
+        for tile, k0, k1, slot in segs:
+            assert 0 <= k0 < k1 <= ksteps
+            for k in range(k0, k1):
+                assert (tile, k) not in covered
+                covered[(tile, k)] = w
+            if slot is not None:
+                assert (w, slot) not in slabs
+                slabs.add((w, slot))
+                assert k1 - k0 >= 4 and ksteps >= 8                                            # no cut shorter than the prologue; short tiles stay whole
+    assert len(covered) == tiles * ksteps
+    # the parts of a tile are consecutive workgroups in K order: the combine adds their slabs in workgroup order
+    for tile in range(tiles):
+        owners = [covered[(tile, k)] for k in range(ksteps)]
+        assert owners == sorted(owners) and set(owners) == set(range(owners[0], owners[-1] + 1))
+    # balance: nobody carries more than the even share plus the snapping distance
+    loads = [sum(k1 - k0 for _, k0, k1, _ in segs) for segs in part]
+    active = [x for x in loads if x]
+    share = tiles * ksteps / len(active)
+    slack = 2 * 4 if ksteps >= 8 else ksteps
+    assert max(loads) <= share + slack + 1 and min(active) >= min(share - slack - 1, 4 if ksteps >= 8 else 1)
+    assert len(active) == G or tiles * ksteps < G * 8 or ksteps < 8
+
