@@ -293,7 +293,7 @@ def per_shape_report(lib, probs, stream) -> dict:
         cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.hgemm_mi355x_plan(p.m, p.n, p.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
         name = lib.hgemm_mi355x_config_name(cfg.value)
-        row["plan"] = {"config": name.decode() if name else "ragged", "splits": sp.value & 0xFFFF, "fused_split_k": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000), "k_stagger": bool(sp.value & 0x40000),
+        row["plan"] = {"config": name.decode() if name else "ragged", "splits": sp.value & 0xFFFF, "fused_split_k": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000),
                        "group_m": gm.value}
         row["roofline"] = roofline_entry(p, row["ours_us"], measured_traffic_bytes(p.mnk))
         out[p.mnk] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in row.items()}
@@ -434,7 +434,7 @@ def main(argv=None):
                                "call each, fp16 N(0,1) operands resident in HBM; replicas per GPU",
                    "batch": args.batch, "timed_region_s": round(elapsed, 3),
                    "accumulate": "fp32 MFMA (both modes; CDNA4 has no fp16-accumulate MFMA)",
-                   "plan": {"config": cname.decode() if cname else "ragged", "splits": sp.value & 0xFFFF, "nt_store": bool(sp.value & 0x20000), "k_stagger": bool(sp.value & 0x40000),
+                   "plan": {"config": cname.decode() if cname else "ragged", "splits": sp.value & 0xFFFF, "nt_store": bool(sp.value & 0x20000),
                             "group_m": gm.value}},
         "roofline": roof,
     }

@@ -491,7 +491,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.k_chunk = K; g.splits = 1; g.tiles_m = g.tiles_n = 1; g.group_m = 1; g.items = 1;
   g.tail_first = 0; g.tail_tiles = 0;
-  g.flags = ((splits_arg & HGEMM_PLAN_NT_STORE) ? 1 : 0) | ((splits_arg & HGEMM_PLAN_K_STAGGER) ? 2 : 0);
+  g.flags = (splits_arg & HGEMM_PLAN_NT_STORE) ? 1 : 0;
 #ifdef HGEMM_ABLATION
   g.debug = g_debug_flags;
 #endif

@@ -150,7 +150,7 @@ struct GemmArgs {
   // Single-launch split-K (EPI_FUSED): one arrival counter per output tile (zero before the launch, reset
   // by the last arriver) and compact per-item slabs partial[item][BM*BN] in the kernel's own lane order.
   unsigned* counters;
-  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE); bit 1: family q's K-stagger variant (HGEMM_PLAN_K_STAGGER, host side only)
+  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE)
 #if HGEMM_FASTDIV
   RasterDiv rd;    // multipliers for the raster map's divisions (set_raster_div on the host, after the fields above are final)
 #endif

@@ -387,7 +387,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
     if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
     else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
     {                                                                                                          \
-      const int s0_ = ((XS || HGEMM_SQ_XSTAGGER) && nxt_nk >= 8) ? (int)(blockIdx.x % NUM_XCD) * (nxt_nk / NUM_XCD) : 0; \
+      const int s0_ = (HGEMM_SQ_XSTAGGER && nxt_nk >= 8) ? (int)(blockIdx.x % NUM_XCD) * (nxt_nk / NUM_XCD) : 0; \
       cur[OP].kbyte = (uint32_t)nxt_kb + (uint32_t)s0_ * (CFG::KT * ROW_BYTES);                                \
       cur[OP].wrap_kt = nxt_nk - s0_;   /* the walk wraps to the item's first stage when kt reaches this */   \
     }                                                                                                          \
@@ -399,7 +399,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
   do {                                                                                       \
     ++cur[OP].kt;                                                                            \
     cur[OP].kbyte += CFG::KT * ROW_BYTES;                                                    \
-    if ((XS || HGEMM_SQ_XSTAGGER) && cur[OP].kt == cur[OP].wrap_kt)                                  \
+    if (HGEMM_SQ_XSTAGGER && cur[OP].kt == cur[OP].wrap_kt)                                  \
       cur[OP].kbyte -= (uint32_t)cur[OP].nk * (CFG::KT * ROW_BYTES);                         \
   } while (0)
 
@@ -438,14 +438,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
   } while (0)
 
 // EPI: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB / SP_EPI_FUSED (as family "s")
-// XS = 1: the per-XCD K stagger as a kernel variant of its own (plan flag HGEMM_PLAN_K_STAGGER; HGEMM_SQ_XSTAGGER above forces it
-// for every launch of an experiment build).  The workgroups of XCD x start every K walk at stage x * nk / 8 and wrap around:
-// a lock-step launch whose rows lie 16-32 KiB apart otherwise reads the same few HBM channels at the same time.  Round-3 map
-// over all 436 family-q plans (tuning/r03_q_plans_stream_*): neutral on average, +4..19 % on the long-K streaming shapes,
-// -1..6 % on the compute-bound ones in isolated launches -- hence a variant the tuned table selects per shape, and the
-// XS = 0 kernels carry no trace of it.  The summation order of a tile changes with the XCD it runs on (deterministic per
-// launch geometry; exact for the reference's 0/1 inputs either way).
-template <class CFG, int EPI, bool XS = false>
+template <class CFG, int EPI>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
   prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)

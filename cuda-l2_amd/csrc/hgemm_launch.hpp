@@ -63,21 +63,14 @@ void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
 template <class CFG>
 void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
   const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-  // plan flag HGEMM_PLAN_K_STAGGER (GemmArgs::flags bit 1): the staggered variants exist for the three epilogues tuned plans
-  // use; a narrow-epilogue launch (N % 8 != 0) ignores the flag
-  const bool xs = (g.flags & 2) != 0 && CFG::MI == 16;
-  if (epi == EPI_FUSED) {
-    if (xs) HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED, CFG::MI == 16>), grid, CFG::THREADS, stream, ts, g);
-    else    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
-  } else if (epi == EPI_SLAB) {
-    if (xs) HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB, CFG::MI == 16>), grid, CFG::THREADS, stream, ts, g);
-    else    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
-  } else if (wide) {
-    if (xs) HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE, CFG::MI == 16>), grid, CFG::THREADS, stream, ts, g);
-    else    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
-  } else {
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
+  else if (wide)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
+  else
     HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
-  }
 }
 
 template <class CFG>

@@ -182,7 +182,6 @@ static double stream_us(F&& launch, std::vector<Buffers>& sets, double seconds, 
 // harness times (a device sync either side of every call), the back-to-back stream is what a model runs; a plan that is level
 // in one and 10 % better in the other should win (16384^2 x 128: 256x128 tiles with streaming C stores 158 / 133 us against
 // 157 / 148 for 128x128 tiles).  Candidates slower than 1.25x the best isolated time are dropped unmeasured.
-static int g_check_plan_flags = 0;     // check --plan-flags F: OR-ed into every plan (HGEMM_PLAN_NT_STORE, HGEMM_PLAN_K_STAGGER)
 static bool g_rank_both = false;
 static bool g_stream_report = false;   // tune --plan-only --baselines --stream
 static bool g_try_nt = false;   // tune --nt: streaming C stores for the winner, judged back to back (HGEMM_PLAN_NT_STORE)
@@ -321,7 +320,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
           if (group > 1 && c < 0) continue;
           for (int rep = 0; rep < (sp > 1 ? 2 : 1); ++rep) {   // split-K twice: the arrival counters must come back to zero
             HIP_OK(hipMemset(s.c, 0xff, cn * 2));  // NaN pattern: unwritten outputs are caught
-            const int st = hgemm_mi355x_launch(c, splits | g_check_plan_flags, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
+            const int st = hgemm_mi355x_launch(c, splits, group, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr);
             hipError_t e = hipDeviceSynchronize();
             ++runs;
             if (st != HGEMM_OK || e != hipSuccess) {
@@ -804,7 +803,6 @@ int main(int argc, char** argv) {
     else if (a == "--nt") g_try_nt = true;
     else if (a == "--rank") g_rank_both = std::string(next()) == "both";
     else if (a == "--stream") g_stream_report = true;
-    else if (a == "--plan-flags") g_check_plan_flags = (int)strtol(next(), nullptr, 0);
     else if (a == "--cand-file") { if (!load_cand_file(next())) { fprintf(stderr, "cannot read --cand-file\n"); return 2; } }
     else if (a == "--configs") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) g_config_filter.push_back(t); }
     else if (a == "--plan-only") g_plan_only = true;

@@ -165,7 +165,7 @@ def main() -> int:
                             "arithmetic_intensity": round(ai, 1)}}
         if s in plans:
             r = plans[s]
-            row["plan"] = {"config": r[3], "splits": r[4] & 0xFFFF, "fused": bool(r[4] & 0x10000), "nt_store": bool(r[4] & 0x20000), "k_stagger": bool(r[4] & 0x40000), "group_m": r[5]}
+            row["plan"] = {"config": r[3], "splits": r[4] & 0xFFFF, "fused": bool(r[4] & 0x10000), "nt_store": bool(r[4] & 0x20000), "group_m": r[5]}
         out.append(row)
     print(json.dumps({"source": "rocprofv3 --pmc, three passes of `hgemm_tune bench --shapes ... --lib --reps 6` (tools/pmc_table.sh), MI355X, N(0,1) operands, "
                                 "isolated launches (profiled clocks run ~5 % above back-to-back clocks; short kernels include dispatch time in GRBM_GUI_ACTIVE)",

@@ -69,13 +69,6 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * two launches shrinks from 3.7 to 2.0 us; 4096^3 -4 %, 8192 x 16384 x 256 -8 %, 16384^2 x 256 +1.5 %: the tuner decides
  * per shape.  Results are bit-identical either way. */
 #define HGEMM_PLAN_NT_STORE 0x20000
-/* Plan flag for the family-q geometries (ignored by the others): per-XCD K stagger -- the workgroups of XCD x start their K
- * walk at stage x * nk / 8 and wrap around, so a launch whose workgroups would otherwise read rows 16-32 KiB apart at the same
- * K offset (the same few HBM channels) spreads over the channels.  Pays on long-K streaming shapes (16384 x 512 x 16384:
- * 284 -> 239 us back to back), costs 1-6 % on compute-bound ones: the tuned table sets it per shape.  The summation order
- * of an output tile then depends on the XCD that computes it (deterministic for a given launch; exact on the reference's
- * 0/1 check inputs either way). */
-#define HGEMM_PLAN_K_STAGGER 0x40000
 
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)

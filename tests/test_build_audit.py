@@ -75,7 +75,7 @@ def test_sp_kernels_do_not_spill_and_leave_room_for_the_agprs(sp_functions):
         # (2) >= 16; only the single-launch split-K form (3: fragments + a combine row live together) may use the file
         # up to the last register -- a compiler bump that costs one more there fails the 256-AGPR check above instead of
         # silently spilling.  The table is printed (pytest -s / on failure) so a creeping allocation is visible early.
-        epi = int(re.search(r"ELi(\d)E(?:Lb[01]E)?EEvNS", name).group(1))      # (family q: ... EPI, then the K-stagger variant flag)
+        epi = int(re.search(r"ELi(\d)EEEvNS", name).group(1))
         bound = {0: 224, 1: 224, 2: 240, 3: 256}[epi]
         print(f"accum_offset {accum.group(1):>3} (bound {bound})  {name}")
         assert int(accum.group(1)) <= bound, f"{name}: {accum.group(1)} VGPRs > {bound} (epilogue class {epi})"

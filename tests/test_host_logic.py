@@ -77,7 +77,7 @@ def test_planner_returns_a_valid_plan(lib, mnk):
     assert lib.hgemm_mi355x_plan(*mnk, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert 0 <= cfg.value < lib.hgemm_mi355x_num_configs()
     count = splits.value & 0xFFFF          # | 0x10000 = HGEMM_SPLITK_FUSED (single-launch form), | 0x20000 = HGEMM_PLAN_NT_STORE
-    assert splits.value & ~0x7FFFF == 0         # | 0x40000 = HGEMM_PLAN_K_STAGGER
+    assert splits.value & ~0x3FFFF == 0
     assert 1 <= count <= max(1, mnk[2] // 64) and group.value >= 1
     assert lib.hgemm_mi355x_model_us(cfg.value, count, *mnk) > 0
     info = (ctypes.c_int * 8)()
@@ -279,9 +279,9 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
     recs = [json.loads(ln) for ln in (PKG / "tuning" / "r03_parity_1000.jsonl").read_text().splitlines()]
     assert len(recs) == 2000 and all(r["pass"] and r["bitwise_equal_unmasked"] for r in recs)
     assert {r["run"] for r in recs} == {"fp32", "fp16"} and len({r["mnk"] for r in recs}) == 1000
-    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), bool(s & 0x40000), g) for (m, n, k, c, s, g) in _tuned_rows()}
+    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), g) for (m, n, k, c, s, g) in _tuned_rows()}
     for r in recs:
-        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"].get("k_stagger", False), r["plan"]["group_m"]) in shipped, r["mnk"]
+        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["group_m"]) in shipped, r["mnk"]
 
 
 def test_analytic_model_picks_near_optimal_plans_on_the_measured_candidates(lib):
@@ -469,5 +469,5 @@ def test_planner_fuzz_every_answer_is_launchable(lib):
         assert 0 <= c.value < n_cfg, (m, n, k, c.value)
         gran = lib.hgemm_mi355x_config_k_granularity(c.value)
         assert k % gran == 0, (m, n, k, lib.hgemm_mi355x_config_name(c.value), gran)
-        assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x7FFFF) == 0 and g.value >= 1
+        assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x3FFFF) == 0 and g.value >= 1
         assert not lib.hgemm_mi355x_config_name(c.value).decode().endswith("_m32") or lib.hgemm_mi355x_config_name(c.value).decode().startswith("t")

@@ -157,7 +157,7 @@ def main(argv=None) -> int:
                            "inputs": "{0,0,1}" if sparse else "{0,1}", "repeats": len(diffs)}
                     if c is None:
                         rec["plan"] = {"config": name.decode() if name else ("ragged" if cfg.value == -2 else "generic"),
-                                       "splits": sp.value & 0xFFFF, "fused": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000), "k_stagger": bool(sp.value & 0x40000),
+                                       "splits": sp.value & 0xFFFF, "fused": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000),
                                        "group_m": gm.value}
                     else:
                         rec["plan"] = {"config": c["config"], "splits": c["splits"], "group_m": c["group_m"]}
