@@ -46,7 +46,10 @@
 #ifndef HGEMM_SQ_XSTAGGER
 #define HGEMM_SQ_XSTAGGER 0   // 1: the workgroups of XCD x start every K walk at stage x * nk / 8 (and wrap around): the
                               // XCDs stop reading the same K offsets at the same time, each XCD's workgroups stay in
-                              // lock-step (their L2 sharing of the A / B panels is untouched)
+                              // lock-step (their L2 sharing of the A / B panels is untouched).
+                              // BROKEN for the non-square members (round 3, `hgemm_tune check --plan-flags`: 256x128, 128x256,
+                              // 192x256, 256x192 compute wrong results with it, the square members are exact;
+                              // profiles/r03_check_q_xstagger_variant_FAILS.log): timing experiments on square tiles only
 #endif
 #ifndef HGEMM_SQ_QORDER
 #define HGEMM_SQ_QORDER 0     // behind Q: 0 = B-fragment reads lead the A pieces, 1 = the pieces lead
