@@ -471,3 +471,47 @@ def test_planner_fuzz_every_answer_is_launchable(lib):
         assert k % gran == 0, (m, n, k, lib.hgemm_mi355x_config_name(c.value), gran)
         assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x3FFFF) == 0 and g.value >= 1
         assert not lib.hgemm_mi355x_config_name(c.value).decode().endswith("_m32") or lib.hgemm_mi355x_config_name(c.value).decode().startswith("t")
+
+
+def test_planner_keeps_the_late_geometries_inside_their_measured_domains(lib):
+    """Round 3, DESIGN.md section 4.8 / 6.5: the first version of the off-grid rules took an 8-wave mid tile for 525 tiles, 24
+    tiles of 256 x 192, and a 192-wide sibling whenever it saved a fraction of a round -- all three measured slower than the
+    corner plans they displaced.  The rules now hold them to <= 512 workgroups, >= 128 tiles, and the 0.87 tile-cost term."""
+    def cfg_of(m, n, k):
+        c, s, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.hgemm_mi355x_plan(m, n, k, ctypes.byref(c), ctypes.byref(s), ctypes.byref(g)) == 0
+        return lib.hgemm_mi355x_config_name(c.value).decode(), s.value & 0xFFFF
+
+    assert "w2x4_m16_s4" not in cfg_of(1332, 3108, 4440)[0] and "w4x2_m16_s4" not in cfg_of(1332, 3108, 4440)[0]
+    assert not cfg_of(1968, 576, 4096)[0].startswith("q256x192")
+    for shape in [(8192, 13824, 5120), (4384, 12288, 3840), (10904, 12288, 2048), (9216, 9216, 4096)]:
+        assert cfg_of(*shape)[0] == "q256x256_w2x2", shape            # the sibling would save < 8 % of a round: not worth its 0.87
+    for shape in [(3072, 3072, 3072), (1536, 6144, 6144), (6144, 6144, 6144), (12288, 1000, 4096)]:
+        assert cfg_of(*shape)[0] == "q192x256_w2x2", shape
+    for shape in [(8192, 1536, 8192), (2048, 6144, 2048)]:
+        assert cfg_of(*shape)[0] == "q256x192_w2x2", shape
+    assert cfg_of(500, 4000, 4096)[0] == "t128x64_w4x2_m16_s4"         # 4 x 63 = 252 tiles: the 8-wave tile's home ground
+
+
+def test_tuned_table_overrides_apply_in_order(tmp_path):
+    """tools/make_tuned_table.py --override A --override B: B replaces A (and the main runs) for the shapes it contains; a shape
+    only in A keeps A's measurements."""
+    import json as _json
+    import sys as _sys
+
+    _sys.path.insert(0, str(PKG / "tools"))
+    import make_tuned_table as mtt
+
+    def rec(mnk, plans):
+        return _json.dumps({"mnk": mnk, "best": {}, "candidates": [{"config": c, "splits": s, "group_m": g, "us": us} for (c, s, g, us) in plans]})
+
+    main, a, b = tmp_path / "main.jsonl", tmp_path / "a.jsonl", tmp_path / "b.jsonl"
+    main.write_text(rec("64_64_64", [("t32x32_w1x1_m16_s4", 1, 1, 5.0)]) + "\n" + rec("128_128_128", [("t64x64_w2x2_m16_s4", 1, 1, 6.0)]) + "\n")
+    a.write_text(rec("64_64_64", [("t64x32_w2x1_m16_s4", 1, 1, 9.0)]) + "\n" + rec("128_128_128", [("t32x64_w1x2_m16_s4", 1, 1, 9.0)]) + "\n")
+    b.write_text(rec("64_64_64", [("t32x64_w1x2_m16_s4", 1, 2, 11.0)]) + "\n")
+    per = mtt.merge_runs([str(main)])
+    for ov in (str(a), str(b)):
+        per.update(mtt.merge_runs([ov]))
+    assert list(per["64_64_64"]) == [("t32x64_w1x2_m16_s4", 1, 2)]        # the later override wins although it is the slowest
+    assert list(per["128_128_128"]) == [("t32x64_w1x2_m16_s4", 1, 1)]     # only the first override knows this shape
+
