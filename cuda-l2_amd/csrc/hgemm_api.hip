@@ -157,6 +157,13 @@ constexpr double kBoundaryUs   = 3.7;    // dependent kernel boundary + launch o
 constexpr double kHbmBytesUs   = 4.6e6;  // ~4.6 TB/s sustained for mixed read/write (fitted)
 constexpr double kCuFlopUs     = 4069.0 * 2000.0;  // fp16 MFMA flop per CU per us at ~2.0 GHz
 
+// persistent workgroups of a stream-K plan: the plan's low 16 bits, or (0 / 1) one resident wave of them
+inline int streamk_grid(const KernelEntry& e, int g_plan) {
+  return g_plan > 1 ? std::min(g_plan, 4096) : kCUs * std::max(1, e.sk_wgs_per_cu);
+}
+// stages closer than this to a tile boundary are not worth a cut (the prologue of a segment is 2-3 stages deep)
+inline int streamk_min_steps(const KernelEntry& e) { return e.kgran >= 256 ? 2 : e.kgran >= 128 ? 3 : 4; }
+
 // Raster group height.  What matters for L2 reuse is the set of tiles an XCD runs CONCURRENTLY
 // (32 CUs x workgroups per CU), not all the tiles it will ever get: consecutive logical ids fill a
 // column of `g` tiles, so `c` concurrent tiles touch g A-panels and c/g B-panels; panel bytes are
@@ -215,6 +222,29 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   }
   const double q_bias = (is_q && !is_q128) ? (K / splits >= 1024 ? 0.99 : 1.01) : 1.0;
   return (kLaunchUs + std::max(main_us, bytes / kHbmBytesUs) + extra) * q_bias;
+}
+
+// Stream-K plan (EPI_STREAMK) of G persistent workgroups: every workgroup walks ~tiles * stages / G pipeline stages at the
+// family's step cost, a cut tile costs one slab round trip (write-through store, arrival, the completer reads the parts).
+// Constants are the data-parallel model's; the tuner measures, this only prunes candidates and ranks off-grid corners.
+double model_us_streamk(const KernelEntry& e, int M, int N, int K, int G) {
+  const long tiles = (long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn);
+  const int stages = (K + e.kgran - 1) / e.kgran;
+  const long total = tiles * stages;
+  G = (int)std::max<long>(1, std::min<long>(G, total));
+  const int conc = (int)std::max<long>(1, std::min<long>(e.sk_wgs_per_cu, (G + kCUs - 1) / kCUs));
+  const int tm = e.bm / e.wm, tn = e.bn / e.wn;
+  const double reuse = (double)tm * tn / (tm + tn);
+  const double eff = 0.62 * std::min(1.0, reuse / 51.0) * (e.wm * e.wn == 8 && e.bm * e.bn <= 128 * 64 ? 1.4 : 1.0);
+  const double step_tp = conc * (2.0 * e.bm * e.bn * e.kgran) / (kCuFlopUs * eff);
+  const double step_lat = (e.name[0] == 'r' ? 0.45 : (e.nbuf >= 3 ? 0.33 : 0.74)) * e.kgran / 64.0 * (e.name[0] == 'r' ? 0.5 : 1.0);
+  const double per_wg = (double)((total + G - 1) / G);
+  const long rounds = (G + (long)kCUs * conc - 1) / ((long)kCUs * conc);
+  const double main_us = rounds * (1.0 + per_wg * std::max(step_tp, step_lat));
+  const long cuts = total % G == 0 && (total / G) % stages == 0 ? 0 : std::min<long>(G, tiles * 2);   // partial segments
+  const double fix_bytes = 2.0 * cuts * e.bm * e.bn * 4.0;
+  const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N) + fix_bytes;
+  return kLaunchUs + std::max(main_us, bytes / kHbmBytesUs) + (cuts ? 1.5 : 0.0);
 }
 
 // K the geometry accepts: a multiple of its stage depth, or any multiple of 8 for the families that zero-fill a
@@ -402,7 +432,16 @@ int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* gro
 
 double hgemm_mi355x_model_us(int config_id, int splits, int M, int N, int K) {
   if (config_id < 0 || config_id >= g_num_kernels || splits < 1 || M <= 0 || N <= 0 || K <= 0) return -1.0;
-  return model_us(g_kernel_table[config_id], M, N, K, splits);
+  const KernelEntry& e = g_kernel_table[config_id];
+  // `splits` as hgemm_mi355x_launch takes it: the plan flags are not a split count (round 3 passed them through: a row with
+  // HGEMM_PLAN_NT_STORE was priced as 131073 splits)
+  if ((splits & HGEMM_PLAN_STREAMK) && e.sk_wgs_per_cu > 0)
+    return model_us_streamk(e, M, N, K, streamk_grid(e, splits & HGEMM_SPLITK_MASK));
+  return model_us(e, M, N, K, std::max(1, splits & HGEMM_SPLITK_MASK));
+}
+
+int hgemm_mi355x_config_streamk(int config_id) {
+  return (config_id >= 0 && config_id < g_num_kernels) ? g_kernel_table[config_id].sk_wgs_per_cu : 0;
 }
 
 int hgemm_mi355x_default_group(int config_id, int M, int N) {
@@ -413,6 +452,8 @@ int hgemm_mi355x_default_group(int config_id, int M, int N) {
 
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits) {
   // upper bound over both split-K forms and every tile size (<= 256): counters + tile-padded fp32 slabs
+  if (splits & HGEMM_PLAN_STREAMK)   // two compact slabs per persistent workgroup, tiles <= 256 x 256
+    return kCounterBytes + (size_t)2 * (size_t)std::min(4096, std::max(1024, splits & HGEMM_SPLITK_MASK)) * 256 * 256 * sizeof(float);
   if ((splits & HGEMM_SPLITK_MASK) <= 1) return 0;
   const size_t mp = ((size_t)M + 255) / 256 * 256, np = ((size_t)N + 255) / 256 * 256;
   return kCounterBytes + (size_t)(splits & HGEMM_SPLITK_MASK) * mp * np * sizeof(float);
@@ -468,6 +509,8 @@ int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream) {
   if (st != HGEMM_OK) return st;
   // split-K slabs of the plan, or the hybrid tail's compact slabs (one 256x256 fp32 tile per resident workgroup at most)
   size_t slab = hgemm_mi355x_workspace_bytes(M, N, splits);
+  if ((splits & HGEMM_PLAN_STREAMK) && cfg >= 0 && g_kernel_table[cfg].sk_wgs_per_cu > 0)   // exactly what the launch will ask for
+    slab = kCounterBytes + (size_t)2 * streamk_grid(g_kernel_table[cfg], splits & HGEMM_SPLITK_MASK) * g_kernel_table[cfg].bm * g_kernel_table[cfg].bn * sizeof(float);
   slab = std::max(slab, kCounterBytes + (size_t)256 * 256 * 256 * sizeof(float)) - kCounterBytes;
   float* slabs = nullptr; unsigned* counters = nullptr;
   const int rc = ensure_workspace(slab, (hipStream_t)stream, &slabs, &counters);
@@ -484,6 +527,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
   if (config_id >= g_num_kernels || config_id < HGEMM_CONFIG_RAGGED) return HGEMM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const bool want_fused = (splits_arg & HGEMM_SPLITK_FUSED) != 0;
+  const bool want_streamk = (splits_arg & HGEMM_PLAN_STREAMK) != 0;
   int splits = splits_arg & HGEMM_SPLITK_MASK;
 
   GemmArgs g;
@@ -492,6 +536,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
   g.k_chunk = K; g.splits = 1; g.tiles_m = g.tiles_n = 1; g.group_m = 1; g.items = 1;
   g.tail_first = 0; g.tail_tiles = 0;
   g.flags = (splits_arg & HGEMM_PLAN_NT_STORE) ? 1 : 0;
+  g.sk = StreamK{1, 0, 0, 1, FastDiv{0u, 0u, 0u}};
 #ifdef HGEMM_ABLATION
   g.debug = g_debug_flags;
 #endif
@@ -529,6 +574,33 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     if (!k_ok(e, K)) return HGEMM_ERR_BAD_ARG;
     const int kgran = e.kgran;
     const int ksteps = (K + kgran - 1) / kgran;
+    // Stream-K (HGEMM_PLAN_STREAMK; the low bits of `splits` are then the number of persistent workgroups): one launch, no
+    // combine kernel.  Not available (family without the kernel, too many tiles for the counter block, no workspace): the
+    // plan degrades to the geometry's plain data-parallel launch, like a split-K plan without workspace.
+    if (want_streamk) {
+      const long total = tiles * ksteps;
+      if (e.sk_wgs_per_cu > 0 && tiles <= (long)kMaxFusedTiles && total < (1L << 30)) {
+        const int min_steps = streamk_min_steps(e);
+        const int G = (int)std::max<long>(1, std::min<long>(streamk_grid(e, splits), std::max<long>(1, total / min_steps)));
+        const size_t slab_bytes = (size_t)2 * G * e.bm * e.bn * sizeof(float);
+        unsigned* counters = nullptr;
+        const int st = slab_bytes < 2147483648ull ? ensure_workspace(slab_bytes, s, &g.partial, &counters) : HGEMM_ERR_NO_WORKSPACE_INTERNAL;
+        if (st == HGEMM_OK) {
+          g.counters = counters;
+          g.group_m = std::max(1, std::min(group_m, g.tiles_m));
+          g.items = (int)tiles;
+          g.sk = make_streamk((int)tiles, ksteps, G, min_steps);
+          set_raster_div(g);
+          e.launch(g, G, s, EPI_STREAMK, timing_slot(true, true));
+          hipError_t err2 = hipGetLastError();
+          if (err2 != hipSuccess) { g_last_hip_error = (int)err2; return HGEMM_ERR_HIP; }
+          return HGEMM_OK;
+        }
+        if (st != HGEMM_ERR_NO_WORKSPACE_INTERNAL) return st;
+        g.partial = nullptr;
+      }
+      splits = 1;
+    }
     splits = std::max(1, std::min(splits, ksteps));
     const int steps_per_split = (ksteps + splits - 1) / splits;
     splits = (ksteps + steps_per_split - 1) / steps_per_split;  // no empty split
@@ -631,6 +703,15 @@ int hgemm_mi355x_selfcheck_raster(int tiles_m, int tiles_n, int group_m, int tai
                                              make_raster_div(tiles_m, tiles_n, group_m, tail_tiles))
                                : raster_ref(bid, tiles_m, tiles_n, group_m, tail_first, tail_tiles);
   out[0] = r.split; out[1] = r.tile; out[2] = r.tile_m; out[3] = r.tile_n;
+  return HGEMM_OK;
+}
+// the stream-K partition as the kernels evaluate it: out[0] = first stage of workgroup w's run (w = G: the total), out[1] = the
+// workgroup that owns stage x
+int hgemm_mi355x_selfcheck_streamk(int tiles, int steps, int G, int min_steps, int w, int x, int out[2]) {
+  if (tiles < 1 || steps < 1 || G < 1 || min_steps < 1 || w < 0 || !out || (long)tiles * steps >= (1L << 30)) return HGEMM_ERR_BAD_ARG;
+  const StreamK sk = make_streamk(tiles, steps, G, min_steps);
+  out[0] = sk_start(sk, w, G);
+  out[1] = (x >= 0 && (long)x < (long)tiles * steps) ? sk_owner(sk, x, G) : -1;
   return HGEMM_OK;
 }
 unsigned hgemm_mi355x_selfcheck_fastdiv(unsigned n, unsigned d) { return d ? fast_div(n, make_fast_div(d)) : 0xFFFFFFFFu; }

@@ -130,6 +130,54 @@ inline RasterDiv make_raster_div(int tiles_m, int tiles_n, int group_m, int tail
   return d;
 }
 
+// ---- stream-K partition (EPI_STREAMK; the reference's H100 tree schedules 48 shapes with cutlass::gemm::StreamKScheduler,
+// kernels/h100_F32F16F16F32/128_4096_16384.cu:79, 16384_512_2048.cu:71-73; every hipBLASLt kernel on this chip is one).
+// The tiles x steps pipeline stages of a GEMM form ONE sequence, tile-major (tiles in raster order, a tile's K stages in
+// order).  Workgroup w of G (after the XCD remap: an XCD owns a contiguous run of w) takes [sk_start(w), sk_start(w + 1)):
+//   base(w) = w * q + min(w, r)          total = tiles * steps = q * G + r: contiguous runs that differ by at most one stage
+//   a boundary closer than `min_steps` to a tile boundary is snapped onto it (a segment shorter than the pipeline prologue
+//   costs more than the imbalance it removes); a tile with fewer than 2 * min_steps stages is never cut.
+// snap() is monotone and so is base(): the starts are non-decreasing without a fix-up pass, some workgroups may get nothing.
+// A run decomposes into segments (tile, [k0, k1)): at most the first and the last are partial.  A partial segment writes its
+// fp32 partial to the compact slab 2 * w + (0: it opens the run, 1: it does not) and adds its stage count to the tile's arrival
+// counter; whoever completes the count adds the tile's slabs in K order (= workgroup order: deterministic) and stores the
+// tile.  Nobody waits for anybody: no co-residency assumption, no deadlock.  The closed form is evaluated by the host (slab
+// sizing, tests: hgemm_mi355x_selfcheck_streamk), by every producer and by the combiner, so they agree by construction;
+// tests/kernel_layout_model.py::streamk_partition is the same map in Python with its invariants.
+struct StreamK {
+  int steps;       // pipeline stages per tile (ceil(K / stage depth))
+  int q, r;        // tiles * steps = q * G + r
+  int min_steps;
+  FastDiv div_steps;
+};
+__host__ __device__ __forceinline__ int sk_start(const StreamK& sk, int w, int G) {
+  if (w <= 0) return 0;
+  const int total = sk.q * G + sk.r;
+  if (w >= G) return total;
+  int x = w * sk.q + (w < sk.r ? w : sk.r);
+  const int t = (int)fast_div((uint32_t)x, sk.div_steps), rem = x - t * sk.steps;
+  if (sk.steps < 2 * sk.min_steps) x += (rem * 2 < sk.steps) ? -rem : sk.steps - rem;
+  else if (rem < sk.min_steps) x -= rem;
+  else if (sk.steps - rem < sk.min_steps) x += sk.steps - rem;
+  return x;
+}
+// the workgroup whose run holds stage x (0 <= x < total): the LAST w with sk_start(w) <= x (its run is not empty then)
+__host__ __device__ __forceinline__ int sk_owner(const StreamK& sk, int x, int G) {
+  int lo = 0, hi = G;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sk_start(sk, mid, G) <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+inline StreamK make_streamk(int tiles, int steps, int G, int min_steps) {   // host side
+  StreamK sk;
+  const long total = (long)tiles * steps;
+  sk.steps = steps; sk.q = (int)(total / G); sk.r = (int)(total % G); sk.min_steps = min_steps;
+  sk.div_steps = make_fast_div((uint32_t)steps);
+  return sk;
+}
+
 struct GemmArgs {
   const f16* A;    // [M][lda]
   const f16* Bt;   // [N][ldb]   (b_col_major: B transposed, K contiguous)
@@ -154,6 +202,8 @@ struct GemmArgs {
 #if HGEMM_FASTDIV
   RasterDiv rd;    // multipliers for the raster map's divisions (set_raster_div on the host, after the fields above are final)
 #endif
+  StreamK sk;      // stream-K launches (EPI_STREAMK) only: the partition of the tile-major K-stage sequence (appended: the
+                   // kernarg offsets of every field above are what the round-3 kernels were validated with)
 #ifdef HGEMM_ABLATION
   int debug;       // tuner-only build (results are garbage): bit 0 skip steady-state LDS-DMA, bit 1 skip the
                    // epilogue stores, bit 2 cut every tile's K loop to two steps, bit 3 every tile stores to tile (0,0)
@@ -243,6 +293,7 @@ __device__ __forceinline__ void prefetch_kernargs() {
 constexpr int EPI_C16    = 0;  // fp16 C, written directly (splits == 1)
 constexpr int EPI_SLAB   = 1;  // fp32 partials to [splits][M][N] (or compact tail slabs); a second kernel combines
 constexpr int EPI_FUSED  = 2;  // single-launch split-K: fp32 partials + arrival counter, the last arriver combines
+constexpr int EPI_STREAMK = 3; // stream-K: one persistent launch over the tile-major K-stage sequence (StreamK above)
 
 // Compile-time geometry of one kernel instantiation.
 template <int BM_, int BN_, int WM_, int WN_, int MI_, int NBUF_>
@@ -535,24 +586,15 @@ __device__ __forceinline__ void stage_tile_tail(__amdgpu_buffer_rsrc_t rsA, __am
 
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <class CFG, int EPI>
-__global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g) {
-  prefetch_kernargs<sizeof(GemmArgs)>();
+// The classic family's main loop for ONE work item: tile (m0, n0), K range [k_begin, k_begin + k_items) in nk pipeline
+// stages (the last one partial when k_items % 64 != 0), accumulators cleared here.  Shared by hgemm_tn_kernel (one item per
+// workgroup) and hgemm_tn_sk_kernel (a run of stream-K segments per workgroup).
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NBUF = CFG::NBUF;
+template <class CFG, class ACC>
+__device__ __forceinline__ void classic_mainloop(const GemmArgs& g, int m0, int n0, int k_begin, int k_items, int nk, char* smem, int lane,
+                                                 int wave, int wave_m, int wave_n, ACC (&acc)[CFG::FM][CFG::FN]) {
+  constexpr int BM = CFG::BM, MI = CFG::MI, NBUF = CFG::NBUF;
   constexpr int FM = CFG::FM, FN = CFG::FN, NW = CFG::NW, NJ = CFG::NJ;
-
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
-
-  const int tid  = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave / CFG::WN;
-  const int wave_n = wave % CFG::WN;
-
-  const TileCoord tc = map_block(g, BM, BN);
-  const int split = tc.split, m0 = tc.m0, n0 = tc.n0, k_begin = tc.k_begin, nk = tc.nk;
-
   // ---- LDS-DMA source addressing ------------------------------------------------------------
   // One descriptor per operand, based at the tile's first row; rows past the matrix edge are
   // clamped to the last valid row (their products are never stored).
@@ -564,7 +606,6 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
   __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, 0x80000000u, 0x00020000);
   // valid 16-byte chunks of the last K-step of this work item (8 = it is a full step)
-  const int k_items = min(g.K, k_begin + g.k_chunk) - k_begin;
   const int tail_chunks = (k_items % BK) ? (k_items % BK) / 8 : 8;
   uint32_t tailmask = 0;
 
@@ -600,8 +641,6 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
   const int a_row_base = wave_m * CFG::TM * ROW_BYTES;
   const int b_row_base = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
 
-  using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
-  acc_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -659,9 +698,31 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
     rd = (rd + 1 == NBUF) ? 0 : rd + 1;
     wr = (wr + 1 == NBUF) ? 0 : wr + 1;
   }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+template <class CFG, int EPI>
+__global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI;
+  constexpr int FM = CFG::FM, FN = CFG::FN;
+
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / CFG::WN;
+  const int wave_n = wave % CFG::WN;
+
+  const TileCoord tc = map_block(g, BM, BN);
+
+  using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
+  acc_t acc[FM][FN];
+  classic_mainloop<CFG>(g, tc.m0, tc.n0, tc.k_begin, min(g.K, tc.k_begin + g.k_chunk) - tc.k_begin, tc.nk, smem, lane, wave, wave_m, wave_n, acc);
 
   // ---- epilogue ----------------------------------------------------------------------------------
-  (void)split;
   if constexpr (EPI == EPI_FUSED) {
     constexpr int NQ = (MI == 16) ? 1 : 4;   // f32x4 quads per accumulator tile
     constexpr int SLAB = BM * BN;
@@ -693,6 +754,139 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
     store_tile<MI, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
   } else {
     store_tile<MI, FM, FN, CFG::TM, CFG::TN, EPI == EPI_SLAB>(g, tc, wave_m, wave_n, lane, acc);
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---- stream-K for the families whose accumulators are C++ values (classic "t", register-staged "r") ------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+// One segment of a workgroup's run.
+struct SkSegment {
+  int tile, k0, k1;   // output tile (raster order), stage range inside it
+  int m0, n0;
+  int slab;           // compact slab of a partial segment (2 * w + 0 / 1)
+  bool whole;         // covers the whole tile: stored directly
+};
+// logical workgroup id: the XCD-bijective remap of map_block (an XCD's workgroups own a contiguous part of the sequence,
+// so the tiles an XCD works on concurrently are a compact patch of the tile grid and share A / B panels in its L2)
+__device__ __forceinline__ int sk_logical_wg() {
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
+  const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// segment that starts at stage x of workgroup w's run [run_begin, run_end)
+__device__ __forceinline__ SkSegment sk_segment(const GemmArgs& g, int w, int run_begin, int run_end, int x, int BM, int BN) {
+  SkSegment s;
+  s.tile = (int)fast_div((uint32_t)x, g.sk.div_steps);
+  s.k0 = x - s.tile * g.sk.steps;
+  s.k1 = min(g.sk.steps, s.k0 + (run_end - x));
+  s.whole = s.k0 == 0 && s.k1 == g.sk.steps;
+  s.slab = 2 * w + (x == run_begin ? 0 : 1);
+#if HGEMM_FASTDIV
+  const RasterPos rp = raster_fast(s.tile, g.tiles_m, g.tiles_n, g.group_m, 0, 0, g.rd);
+#else
+  const RasterPos rp = raster_ref(s.tile, g.tiles_m, g.tiles_n, g.group_m, 0, 0);
+#endif
+  s.m0 = rp.tile_m * BM;
+  s.n0 = rp.tile_n * BN;
+  return s;
+}
+// Arrival of a partial segment (its slab stores were issued by every thread): true in every thread of the workgroup that
+// completes the tile's stage count.  Same visibility protocol as fused_publish_and_vote (write-through slabs, vmcnt(0),
+// barrier, one relaxed agent-scope fetch_add); `lds_flag` is a word no in-flight LDS traffic targets.
+__device__ __forceinline__ bool sk_publish_and_vote(const GemmArgs& g, const SkSegment& s, volatile unsigned* lds_flag, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned mine = (unsigned)(s.k1 - s.k0);
+    const unsigned old = __hip_atomic_fetch_add(g.counters + s.tile, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (old + mine == (unsigned)g.sk.steps);
+    if (last) __hip_atomic_store(g.counters + s.tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *lds_flag != 0u;
+}
+
+// Epilogue of one segment: a whole tile is stored directly; a partial one goes to its slab, and the workgroup that completes
+// the tile adds the tile's slabs in K order and stores it.
+template <class CFG, class ACC>
+__device__ __forceinline__ void sk_epilogue(const GemmArgs& g, const SkSegment& s, ACC (&acc)[CFG::FM][CFG::FN], volatile unsigned* lds_flag,
+                                            int tid, int lane, int wave_m, int wave_n) {
+  constexpr int MI = CFG::MI, FM = CFG::FM, FN = CFG::FN;
+  constexpr int NQ = (MI == 16) ? 1 : 4, SLAB = CFG::BM * CFG::BN;
+  TileCoord tc;
+  tc.split = 0; tc.m0 = s.m0; tc.n0 = s.n0; tc.k_begin = 0; tc.nk = 0; tc.tile = s.tile; tc.item = s.tile; tc.slab = nullptr; tc.slab_ld = 0;
+  if (s.whole) {
+    store_tile<MI, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rsP = fused_rsrc(g);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+        fused_store(rsP, fused_off<CFG::THREADS>(s.slab, SLAB, (i * FN + j) * NQ + q, tid), v);
+      }
+  if (!sk_publish_and_vote(g, s, lds_flag, tid)) return;
+  // the tile's parts are the runs of consecutive workgroups, in K order
+  const int G = gridDim.x, t0 = s.tile * g.sk.steps, t1 = t0 + g.sk.steps;
+  bool first = true;
+  for (int w = sk_owner(g.sk, t0, G); w < G; ++w) {
+    const int b = sk_start(g.sk, w, G), e = sk_start(g.sk, w + 1, G);
+    if (b >= t1) break;
+    if (min(e, t1) <= max(b, t0)) continue;             // (an empty run)
+    const int slab = 2 * w + (b >= t0 ? 0 : 1);         // the part opens w's run, or closes it
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(slab, SLAB, (i * FN + j) * NQ + q, tid));
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) acc[i][j][q * 4 + e2] = first ? v[e2] : acc[i][j][q * 4 + e2] + v[e2];
+        }
+    first = false;
+  }
+  store_tile<MI, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+// Stream-K on the classic family: one persistent launch of G workgroups, each walking its run of the sequence.
+template <class CFG>
+__global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sk_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI;
+  constexpr int FM = CFG::FM, FN = CFG::FN;
+
+  // the ring + the vote word behind it (ONE LDS object, see hgemm_kernel_sp.hpp)
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / CFG::WN;
+  const int wave_n = wave % CFG::WN;
+
+  const int G = gridDim.x, w = sk_logical_wg();
+  const int run_begin = sk_start(g.sk, w, G), run_end = sk_start(g.sk, w + 1, G);
+  using acc_t = typename std::conditional<MI == 16, f32x4, f32x16>::type;
+#pragma clang loop unroll(disable)
+  for (int x = run_begin; x < run_end;) {
+    const SkSegment s = sk_segment(g, w, run_begin, run_end, x, BM, BN);
+    // every wave is done with the previous segment's last stage (and with the vote word) before the ring is refilled
+    if (x != run_begin) __syncthreads();
+    const int k_begin = s.k0 * BK, k_items = min(g.K, s.k1 * BK) - k_begin;
+    acc_t acc[FM][FN];
+    classic_mainloop<CFG>(g, s.m0, s.n0, k_begin, k_items, s.k1 - s.k0, smem, lane, wave, wave_m, wave_n, acc);
+    sk_epilogue<CFG>(g, s, acc, (volatile unsigned*)(smem + CFG::LDS_BYTES), tid, lane, wave_m, wave_n);
+    x += s.k1 - s.k0;
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }

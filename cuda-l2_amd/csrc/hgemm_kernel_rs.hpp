@@ -80,24 +80,33 @@ __device__ __forceinline__ void classic_epilogue(const GemmArgs& g, const TileCo
 #endif
 }
 
-template <class CFG, int EPI>
-// two workgroups per CU wherever the tile allows it (second argument = waves per SIMD: <= 256 registers)
-__global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) ? 2 : 1) hgemm_tn_rs_kernel(const GemmArgs g) {
-  prefetch_kernargs<sizeof(GemmArgs)>();
+// cache policy of the operand loads (experiment knob HGEMM_RS_NT: 0 = default, 1 = the STREAMED operand -- the one
+// with more rows, read exactly once -- is loaded non-temporally, 2 = both)
+#ifndef HGEMM_RS_NT
+#define HGEMM_RS_NT 0
+#endif
+// K stagger (Tensile's StaggerU): workgroup w starts its K walk at stage (w * HGEMM_RS_STAGGER) mod nk and wraps
+// around, so the workgroups of a launch do not all read the same K offset of their rows at the same time (row
+// stride = K * 2 B is a large power of two on the grid shapes: identical low address bits = the same few HBM
+// channels; measured: 16384 x 64 x 16384 115 -> 96 us).  The summation order of a tile changes with its
+// coordinates, deterministically.
+#ifndef HGEMM_RS_STAGGER
+#define HGEMM_RS_STAGGER 3
+#endif
+#ifndef HGEMM_RS_STAGGER_MODE
+#define HGEMM_RS_STAGGER_MODE 0   // 0: per work item; 1: per XCD (blockIdx % 8): an XCD's workgroups stay in lock-step; 2: item % 8
+#endif
+
+// Family r's main loop for ONE work item: tile (m0, n0), nk stages of BKS halfs from K offset k_begin, accumulators cleared
+// here; `tile_id` seeds the K stagger (built from the item's COORDINATES, not from its raster position: the summation order
+// of an output tile must not depend on the raster group the caller or the tuner picked).  Shared by hgemm_tn_rs_kernel (one
+// item per workgroup) and hgemm_tn_rs_sk_kernel (a run of stream-K segments per workgroup).
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, THREADS = CFG::THREADS;
+template <class CFG>
+__device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, int k_begin, int nk, unsigned tile_id, char* smem, int tid,
+                                            int lane, int wave_m, int wave_n, f32x4 (&acc)[CFG::FM][CFG::FN]) {
+  constexpr int BM = CFG::BM, FM = CFG::FM, FN = CFG::FN, THREADS = CFG::THREADS;
   constexpr int RB = CFG::RB, NCH = CFG::NCH, KS = CFG::KS, CA = CFG::CA, CB = CFG::CB, BKS = CFG::BKS;
-
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
-
-  const int tid  = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave / CFG::WN, wave_n = wave % CFG::WN;
-
-  const TileCoord tc = map_block(g, BM, BN);
-  const int nk = tc.nk / (BKS / BK);          // stages of this work item (host: K chunk % BKS == 0)
-
   // ---- addressing of this thread's chunks ------------------------------------------------------------------------
   // chunk id = tid + p * THREADS: row id / NCH, chunk id % NCH -> a wave covers 64 / NCH rows x RB contiguous bytes.
   // THREADS is a multiple of NCH, so every chunk p of a thread has the same column c and row r0 + p * RP: ONE
@@ -114,12 +123,12 @@ __global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) 
     const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes));
     return __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, nrec, 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t rsA = rsrc_of(g.A + (size_t)tc.m0 * g.lda, ((size_t)(g.M - tc.m0) * g.lda) * 2);
-  const __amdgpu_buffer_rsrc_t rsB = rsrc_of(g.Bt + (size_t)tc.n0 * g.ldb, ((size_t)(g.N - tc.n0) * g.ldb) * 2);
+  const __amdgpu_buffer_rsrc_t rsA = rsrc_of(g.A + (size_t)m0 * g.lda, ((size_t)(g.M - m0) * g.lda) * 2);
+  const __amdgpu_buffer_rsrc_t rsB = rsrc_of(g.Bt + (size_t)n0 * g.ldb, ((size_t)(g.N - n0) * g.ldb) * 2);
   const uint32_t voff_a = ((uint32_t)r0 * (uint32_t)g.lda + (uint32_t)c0 * 8u) * 2u;
   const uint32_t voff_b = ((uint32_t)r0 * (uint32_t)g.ldb + (uint32_t)c0 * 8u) * 2u;
   const uint32_t step_a = (uint32_t)RP * (uint32_t)g.lda * 2u, step_b = (uint32_t)RP * (uint32_t)g.ldb * 2u;
-  const uint32_t kbyte0 = (uint32_t)tc.k_begin * 2u;
+  const uint32_t kbyte0 = (uint32_t)k_begin * 2u;
   // LDS slot of chunk p: row r0 + p*RP, slot c0 ^ (row & 15).  RP = 16: the XOR term is the same for every p;
   // RP = 8: it flips bit 3 of the slot (= byte bit 7) for odd p.  So: one base, one XOR constant, immediates.
   const int lds_base = r0 * RB + ((c0 ^ (r0 & 15)) << 4);
@@ -131,35 +140,15 @@ __global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) 
   const int a_row_base = wave_m * CFG::TM * RB;
   const int b_row_base = (BM + wave_n * CFG::TN) * RB;
 
-  f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f16x8 ra0[CA], rb0[CB], ra1[CA], rb1[CB];      // two stages in flight
-  // cache policy of the operand loads (experiment knob HGEMM_RS_NT: 0 = default, 1 = the STREAMED operand -- the one
-  // with more rows, read exactly once -- is loaded non-temporally, 2 = both)
-#ifndef HGEMM_RS_NT
-#define HGEMM_RS_NT 0
-#endif
   constexpr int kAuxNt = 2;   // buffer aux operand: bit 1 = nt
   const bool nt_a = HGEMM_RS_NT == 2 || (HGEMM_RS_NT == 1 && g.M >= g.N);
   const bool nt_b = HGEMM_RS_NT == 2 || (HGEMM_RS_NT == 1 && g.M < g.N);
-  // K stagger (Tensile's StaggerU): workgroup w starts its K walk at stage (w * HGEMM_RS_STAGGER) mod nk and wraps
-  // around, so the workgroups of a launch do not all read the same K offset of their rows at the same time (row
-  // stride = K * 2 B is a large power of two on the grid shapes: identical low address bits = the same few HBM
-  // channels; measured: 16384 x 64 x 16384 115 -> 96 us).  The summation order of a tile changes with its
-  // coordinates, deterministically.
-#ifndef HGEMM_RS_STAGGER
-#define HGEMM_RS_STAGGER 3
-#endif
-#ifndef HGEMM_RS_STAGGER_MODE
-#define HGEMM_RS_STAGGER_MODE 0   // 0: per work item; 1: per XCD (blockIdx % 8): an XCD's workgroups stay in lock-step; 2: item % 8
-#endif
-  // (the id is built from the tile's COORDINATES, not from its raster position: the summation order of an output
-  // tile must not depend on the raster group the caller or the tuner picked)
-  const unsigned tile_id = (unsigned)(tc.m0 / BM) + (unsigned)(tc.n0 / BN) * (unsigned)g.tiles_m + (unsigned)tc.split * 5u;
   const unsigned stg_id = HGEMM_RS_STAGGER_MODE == 1 ? (blockIdx.x % NUM_XCD) * (unsigned)max(1, nk / NUM_XCD)
                         : HGEMM_RS_STAGGER_MODE == 2 ? (tile_id % 8u) * (unsigned)max(1, nk / 8) : tile_id * (unsigned)HGEMM_RS_STAGGER;
   const int stage0 = HGEMM_RS_STAGGER ? (int)(stg_id % (unsigned)nk) : 0;
@@ -236,9 +225,65 @@ __global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) 
 #undef RS_STAGE
 #undef RS_WRITE
 #undef RS_COMPUTE
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+template <class CFG, int EPI>
+// two workgroups per CU wherever the tile allows it (second argument = waves per SIMD: <= 256 registers)
+__global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) ? 2 : 1) hgemm_tn_rs_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, BKS = CFG::BKS;
+
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / CFG::WN, wave_n = wave % CFG::WN;
+
+  const TileCoord tc = map_block(g, BM, BN);
+  const int nk = tc.nk / (BKS / BK);          // stages of this work item (host: K chunk % BKS == 0)
+  const unsigned tile_id = (unsigned)(tc.m0 / BM) + (unsigned)(tc.n0 / BN) * (unsigned)g.tiles_m + (unsigned)tc.split * 5u;
+
+  f32x4 acc[FM][FN];
+  rs_mainloop<CFG>(g, tc.m0, tc.n0, tc.k_begin, nk, tile_id, smem, tid, lane, wave_m, wave_n, acc);
 
   if constexpr (EPI == EPI_FUSED) __syncthreads();   // the vote word lives at smem[0]: every wave must be done reading
   classic_epilogue<CFG, EPI>(g, tc, acc, smem, tid, lane, wave_m, wave_n);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// Stream-K on family r (hgemm_kernel.hpp: StreamK): the skinny streaming shapes get their exact chip fill (12288 x 128 x 8192:
+// 96 tiles of 128 x 128 on 256 CUs) and every workgroup of a cut tile starts its K walk somewhere else.
+template <class CFG>
+__global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) ? 2 : 1) hgemm_tn_rs_sk_kernel(const GemmArgs g) {
+  prefetch_kernargs<sizeof(GemmArgs)>();
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, BKS = CFG::BKS;
+
+  // the stage buffer + the vote word behind it (ONE LDS object)
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / CFG::WN, wave_n = wave % CFG::WN;
+
+  const int G = gridDim.x, w = sk_logical_wg();
+  const int run_begin = sk_start(g.sk, w, G), run_end = sk_start(g.sk, w + 1, G);
+#pragma clang loop unroll(disable)
+  for (int x = run_begin; x < run_end;) {
+    const SkSegment s = sk_segment(g, w, run_begin, run_end, x, BM, BN);
+    // every wave is done with the previous segment's last stage (and with the vote word) before the buffer is rewritten
+    if (x != run_begin) __syncthreads();
+    // (the stagger seed depends on the tile's coordinates and on where the segment starts, not on the raster group)
+    const unsigned tile_id = (unsigned)(s.m0 / BM) + (unsigned)(s.n0 / BN) * (unsigned)g.tiles_m + (unsigned)s.k0 * 5u;
+    f32x4 acc[FM][FN];
+    rs_mainloop<CFG>(g, s.m0, s.n0, s.k0 * BKS, s.k1 - s.k0, tile_id, smem, tid, lane, wave_m, wave_n, acc);
+    sk_epilogue<CFG>(g, s, acc, (volatile unsigned*)(smem + CFG::LDS_BYTES), tid, lane, wave_m, wave_n);
+    x += s.k1 - s.k0;
+  }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

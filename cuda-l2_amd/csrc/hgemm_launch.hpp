@@ -7,7 +7,8 @@
 
 namespace hgemm_mi355x {
 
-// One thunk per geometry; `epi` selects the epilogue (EPI_C16 / EPI_SLAB / EPI_FUSED).  No per-call
+// One thunk per geometry; `epi` selects the epilogue (EPI_C16 / EPI_SLAB / EPI_FUSED) or, for the classic and the
+// register-staged family, the stream-K kernel (EPI_STREAMK: `grid` is then the number of persistent workgroups).  No per-call
 // attribute setting, allocation or synchronisation happens here (the reference calls
 // cudaFuncSetAttribute on every invocation, kernels/a100_F32F16F16F32/64_4096_64.cu:256-261).
 //
@@ -39,7 +40,11 @@ inline TimingSlot timing_slot(bool first, bool last) {
 
 template <class CFG>
 void launch_cfg(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
-  if (epi == EPI_FUSED)
+  if (epi == EPI_STREAMK) {
+    // (the 256 x 256 members have no stream-K kernel: with 128 accumulator registers per lane the combine spills, and a
+    // 256 KiB slab per cut is more than the imbalance it would remove -- family q's hybrid tail covers those shapes)
+    if constexpr (CFG::BM * CFG::BN <= 256 * 128) HGEMM_LAUNCH((hgemm_tn_sk_kernel<CFG>), grid, CFG::THREADS, stream, ts, g);
+  } else if (epi == EPI_FUSED)
     HGEMM_LAUNCH((hgemm_tn_kernel<CFG, EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
   else if (epi == EPI_SLAB)
     HGEMM_LAUNCH((hgemm_tn_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
@@ -75,7 +80,9 @@ void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
 
 template <class CFG>
 void launch_rs(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
-  if (epi == EPI_FUSED)
+  if (epi == EPI_STREAMK)
+    HGEMM_LAUNCH((hgemm_tn_rs_sk_kernel<CFG>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_FUSED)
     HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
   else if (epi == EPI_SLAB)
     HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
@@ -93,6 +100,7 @@ struct KernelEntry {
   int kgran;           // K granularity of one pipeline stage (64, or 128 / 256 for the deep-stage members): every
                        // split-K chunk is a multiple, and so is K unless `ktail`
   bool ktail;          // the kernel zero-fills a partial last K-step by itself: any K % 8 == 0 is accepted
+  int sk_wgs_per_cu;   // > 0: the family has a stream-K kernel (EPI_STREAMK); workgroups of it one CU holds (default G = 256 x this)
 };
 
 extern const KernelEntry g_kernel_table[];

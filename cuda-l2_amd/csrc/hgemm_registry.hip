@@ -23,13 +23,21 @@ namespace hgemm_mi355x {
 // The table holds host function pointers: keep it out of the device pass.
 #if !defined(__HIP_DEVICE_COMPILE__)
 thread_local LaunchTiming t_launch_timing;
+// stream-K workgroups of a classic geometry one CU holds: LDS, 8 waves per SIMD, and the accumulator + fragment registers of a
+// wave (512 per SIMD lane); at most 4 (more persistent workgroups only mean more slabs)
+constexpr int sk_residency(int lds_bytes, int nw, int acc_regs) {
+  const int by_lds = 160 * 1024 / lds_bytes, by_waves = 32 / nw, by_regs = 512 / (acc_regs + 64) * 4 / nw;
+  const int r = by_lds < by_waves ? (by_lds < by_regs ? by_lds : by_regs) : (by_waves < by_regs ? by_waves : by_regs);
+  return acc_regs * 64 * nw > 256 * 128 ? 0 : r < 1 ? 1 : r > 4 ? 4 : r;   // (no stream-K kernel beyond 256 x 128: hgemm_launch.hpp)
+}
 #define HGEMM_STR2(x) #x
 #define HGEMM_STR(x) HGEMM_STR2(x)
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)                                                    \
   {"t" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m" HGEMM_STR(MI)  \
    "_s" HGEMM_STR(NB),                                                                         \
    BM, BN, WM, WN, MI, NB, Cfg<BM, BN, WM, WN, MI, NB>::THREADS,                                \
-   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true, 64, true},
+   Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES, &launch_cfg<Cfg<BM, BN, WM, WN, MI, NB>>, 0, true, 64, true,                      \
+   sk_residency(Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES + 64, Cfg<BM, BN, WM, WN, MI, NB>::NW, BM * BN / (64 * Cfg<BM, BN, WM, WN, MI, NB>::NW))},
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)
 #define HGEMM_RS(G, BM, BN, BKS)
@@ -47,14 +55,14 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)                                                          \
   {HGEMM_SP_NAME_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2,                                      \
    CfgSP<BM, BN, WM, WN, MI>::THREADS, CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64,                  \
-   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64)), true, 64, false},
+   &launch_sp<CfgSP<BM, BN, WM, WN, MI>>, 256 * (160 * 1024 / (CfgSP<BM, BN, WM, WN, MI>::LDS_BYTES + 64)), true, 64, false, 0},
 #define HGEMM_SQ_NAME_1_16(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
 #define HGEMM_SQ_NAME_2_16(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_k128"
 #define HGEMM_SQ_NAME_1_32(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m32"
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)                                                                     \
   {HGEMM_SQ_NAME_##KT##_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2, CfgSQ<BM, BN, WM, WN, KT, MI>::THREADS,      \
    CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>,                      \
-   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64)), true, 64 * KT, false},
+   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64)), true, 64 * KT, false, 0},
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
@@ -65,7 +73,7 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)
 #define HGEMM_RS(G, BM, BN, BKS)                                                                            \
   {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS), BM, BN, 2, 2, 16, 1, CfgRS<BM, BN, BKS>::THREADS,  \
-   CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS, false},
+   CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS, false, (BM * BN <= 64 * 128) ? 2 : 1},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG

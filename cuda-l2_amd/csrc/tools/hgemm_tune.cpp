@@ -3,7 +3,7 @@
 //   hgemm_tune check [--shapes M_N_K,...] [--configs a,b]   every (or the named) geometry x split-K form, BIT-EXACT against an exact
 //                                                     integer reference on the reference's {0,1} inputs
 //                                                     (zero_one_correctness_check.py:65-92,263-268)
-//   hgemm_tune tune  --shapes M_N_K,... | --shape-file F  [--out F.jsonl] [--keep R] [--baselines]
+//   hgemm_tune tune  --shapes M_N_K,... | --shape-file F  [--out F.jsonl] [--keep R] [--baselines] [--fused] [--streamk] [--nt]
 //                                                     time candidate plans, print one JSON line per shape
 //   hgemm_tune bench --shape M_N_K [--config NAME --splits S --group G] [--reps N] [--lib]
 //                                                     run one plan N times (for rocprofv3)
@@ -214,6 +214,7 @@ static bool load_cand_file(const char* path) {
   return true;
 }
 static bool g_fused_too = false;               // --fused: also time the single-launch form of every split-K plan
+static bool g_streamk_too = false;             // --streamk: also time the stream-K plans (HGEMM_PLAN_STREAMK | workgroups)
 
 static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_cand) {
   std::vector<Plan> all;
@@ -236,6 +237,12 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
       if (s > 1 && g_fused_too)
         all.push_back({c, s | HGEMM_SPLITK_FUSED, default_group(c, sh), hgemm_mi355x_model_us(c, s, sh.M, sh.N, sh.K) * 1.001});
     }
+    // stream-K plans of the geometries that have the kernel: one, two, ... resident workgroups per CU
+    if (g_streamk_too)
+      for (int r = 1; r <= hgemm_mi355x_config_streamk(c); ++r) {
+        const int plan = HGEMM_PLAN_STREAMK | (256 * r);
+        all.push_back({c, plan, default_group(c, sh), hgemm_mi355x_model_us(c, plan, sh.M, sh.N, sh.K)});
+      }
   }
   std::sort(all.begin(), all.end(), [](const Plan& a, const Plan& b) { return a.model_us < b.model_us; });
   std::vector<Plan> out;
@@ -312,11 +319,16 @@ static int cmd_check(const std::vector<Shape>& shapes) {
       const char* cname = c >= 0 ? hgemm_mi355x_config_name(c) : (c == HGEMM_CONFIG_GENERIC ? "generic" : "ragged");
       if (!g_config_filter.empty() && std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) == g_config_filter.end())
         continue;   // --configs: only these (the special ids are "generic" / "ragged")
-      for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED}) {
-        const int sp = splits & HGEMM_SPLITK_MASK;
-        if (sp > 1 && (c < 0 || sh.K / 64 < sp)) continue;
+      // stream-K forms (geometries that have the kernel): one resident wave of workgroups, and small odd grids that cut tiles
+      // at odd stages and give every workgroup several segments
+      for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED, HGEMM_PLAN_STREAMK, 5 | HGEMM_PLAN_STREAMK,
+                         37 | HGEMM_PLAN_STREAMK, 300 | HGEMM_PLAN_STREAMK}) {
+        const bool sk = (splits & HGEMM_PLAN_STREAMK) != 0;
+        const int sp = sk ? 2 : (splits & HGEMM_SPLITK_MASK);   // (sp > 1: run twice, one raster group)
+        if (sk && (c < 0 || hgemm_mi355x_config_streamk(c) <= 0)) continue;
+        if (!sk && sp > 1 && (c < 0 || sh.K / 64 < sp)) continue;
         for (int group : {1, 4}) {
-          if (group > 1 && sp > 1) continue;
+          if (group > 1 && sp > 1 && !sk) continue;
           if (group > 1 && c < 0) continue;
           for (int rep = 0; rep < (sp > 1 ? 2 : 1); ++rep) {   // split-K twice: the arrival counters must come back to zero
             HIP_OK(hipMemset(s.c, 0xff, cn * 2));  // NaN pattern: unwritten outputs are caught
@@ -324,7 +336,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
             hipError_t e = hipDeviceSynchronize();
             ++runs;
             if (st != HGEMM_OK || e != hipSuccess) {
-              printf("FAIL %d_%d_%d %s s=%d%s g=%d: status %d hip %d\n", sh.M, sh.N, sh.K, cname, sp, sp != splits ? "(fused)" : "", group, st, (int)e);
+              printf("FAIL %d_%d_%d %s s=%d%s g=%d: status %d hip %d\n", sh.M, sh.N, sh.K, cname, splits & HGEMM_SPLITK_MASK, sk ? "(stream-K)" : sp != splits ? "(fused)" : "", group, st, (int)e);
               ++failures;
               if (e != hipSuccess) return 3;
               continue;
@@ -337,8 +349,8 @@ static int cmd_check(const std::vector<Shape>& shapes) {
                 ++bad;
               }
             if (bad) {
-              printf("FAIL %d_%d_%d %s s=%d%s g=%d: %zu/%zu elements differ from the exact result\n", sh.M, sh.N, sh.K, cname, sp,
-                     sp != splits ? "(fused)" : "", group, bad, cn);
+              printf("FAIL %d_%d_%d %s s=%d%s g=%d: %zu/%zu elements differ from the exact result\n", sh.M, sh.N, sh.K, cname, splits & HGEMM_SPLITK_MASK,
+                     sk ? "(stream-K)" : sp != splits ? "(fused)" : "", group, bad, cn);
               ++failures;
             }
           }
@@ -401,7 +413,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       if (it != g_cand_file.end())
         for (Plan p : it->second) {
           if (sh.K % hgemm_mi355x_config_k_granularity(p.cfg) != 0) continue;
-          p.model_us = hgemm_mi355x_model_us(p.cfg, p.splits & HGEMM_SPLITK_MASK, sh.M, sh.N, sh.K);
+          p.model_us = hgemm_mi355x_model_us(p.cfg, p.splits, sh.M, sh.N, sh.K);   // (takes `splits` as the launch does)
           cands.push_back(p);
         }
       if (cands.empty()) cands = candidates(sh, keep_ratio, std::min(max_cand, 6));   // a shape the file does not know
@@ -467,7 +479,9 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     // the epilogue instead of at the end-of-kernel release), so it is judged in back-to-back mode, plain and NT interleaved
     // twice; adopted when both repetitions agree and the gain is at least 1 %.
     double nt_plain_us = -1, nt_us = -1;
-    if (g_try_nt && !g_plan_only && res[0].p.cfg >= 0 && (res[0].p.splits & HGEMM_SPLITK_MASK) == 1 && (double)sh.M * sh.N >= 512.0 * 512.0) {
+    double nt_iso_us = -1, nt_plain_iso_us = -1;
+    if (g_try_nt && !g_plan_only && res[0].p.cfg >= 0 && ((res[0].p.splits & HGEMM_SPLITK_MASK) == 1 || (res[0].p.splits & HGEMM_PLAN_STREAMK)) &&
+        (double)sh.M * sh.N >= 512.0 * 512.0) {
       Plan pp = res[0].p, pn = res[0].p;
       pn.splits |= HGEMM_PLAN_NT_STORE;
       auto lp = [&](Buffers& s) { return hgemm_mi355x_launch(pp.cfg, pp.splits, pp.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr); };
@@ -477,8 +491,14 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       const double p2 = stream_us(lp, sets, box, e0, e1, res[0].us), n2 = stream_us(ln, sets, box, e0, e1, res[0].us);
       nt_plain_us = std::min(p1, p2); nt_us = std::min(n1, n2);
       if (n1 < p1 * 0.99 && n2 < p2 * 0.99 && std::max(n1, n2) < std::min(p1, p2)) {
-        // keep the isolated time of the plain form as the plan's time (the table compares isolated times), scaled by the gain
-        res.insert(res.begin(), Res{pn, res[0].us * nt_us / nt_plain_us});
+        // adopted on the back-to-back figures; the record carries the NT form's own MEASURED isolated time (round 3 wrote a
+        // synthetic one: the plain form's time scaled by the stream gain)
+        nt_plain_iso_us = res[0].iso_us > 0 ? res[0].iso_us : res[0].us;
+        const int reps_nt = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, nt_plain_iso_us)));
+        nt_iso_us = time_us(ln, sets, 2, reps_nt, e0, e1);
+        Res rn{pn, g_rank_both ? std::sqrt(nt_iso_us * nt_us) : nt_iso_us};
+        rn.iso_us = nt_iso_us; rn.stream = nt_us;
+        res.insert(res.begin(), rn);
       }
     }
     double rb_nn = -1, rb_tn = -1, lt_nn = -1, lt_tn = -1;
@@ -492,7 +512,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     // tune --plan-only --baselines --stream: the same comparison back to back (what a model runs: launches queue behind each
     // other, the end-of-kernel release and the clocks of a busy device are part of the figure), short boxes
     double st_ours = -1, st_lt_nn = -1, st_lt_tn = -1;
-    if (g_plan_only && baselines && g_stream_report) {
+    if (baselines && g_stream_report) {
       const double box = flops > 1.5e12 ? 0.012 : 0.008;
       const Plan p = res[0].p;
       st_ours = stream_us([&](Buffers& s) { return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr); },
@@ -516,9 +536,9 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       }
     }
     // "splits" is the value to pass to hgemm_mi355x_launch (split count | HGEMM_SPLITK_FUSED); "fused" repeats the flag
-    fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"fused\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
+    fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"fused\": %d, \"streamk\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
             sh.M, sh.N, sh.K, hgemm_mi355x_config_name(res[0].p.cfg), res[0].p.splits, (res[0].p.splits & HGEMM_SPLITK_FUSED) ? 1 : 0,
-            res[0].p.group_m, res[0].us, flops / res[0].us * 1e-6);
+            (res[0].p.splits & HGEMM_PLAN_STREAMK) ? 1 : 0, res[0].p.group_m, res[0].us, flops / res[0].us * 1e-6);
     if (g_rank_both && res[0].stream > 0) fprintf(out, ", \"rank\": \"sqrt(isolated_us * stream_us)\"");
     if (baselines)
       fprintf(out, ", \"rocblas_nn_us\": %.3f, \"rocblas_tn_us\": %.3f, \"hipblaslt_heur_nn_us\": %.3f, \"hipblaslt_heur_tn_us\": %.3f",
@@ -527,6 +547,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       fprintf(out, ", \"hipblaslt_auto_nn_us\": %.3f, \"hipblaslt_auto_tn_us\": %.3f, \"hipblaslt_auto_candidates\": [%d, %d]", at_nn, at_tn,
               at_cand_nn, at_cand_tn);
     if (nt_us > 0) fprintf(out, ", \"stream_plain_us\": %.3f, \"stream_nt_us\": %.3f", nt_plain_us, nt_us);
+    if (nt_iso_us > 0) fprintf(out, ", \"nt_adopted_on\": \"stream\", \"isolated_plain_us\": %.3f, \"isolated_nt_us\": %.3f", nt_plain_iso_us, nt_iso_us);
     if (st_ours > 0)
       fprintf(out, ", \"stream_us\": %.3f, \"hipblaslt_heur_tn_stream_us\": %.3f, \"hipblaslt_heur_nn_stream_us\": %.3f", st_ours, st_lt_tn, st_lt_nn);
     fprintf(out, ", \"candidates\": [");
@@ -800,6 +821,7 @@ int main(int argc, char** argv) {
     else if (a == "--out") out_path = next();
     else if (a == "--autotune") autotune = true;
     else if (a == "--fused") g_fused_too = true;
+    else if (a == "--streamk") g_streamk_too = true;
     else if (a == "--nt") g_try_nt = true;
     else if (a == "--rank") g_rank_both = std::string(next()) == "both";
     else if (a == "--stream") g_stream_report = true;

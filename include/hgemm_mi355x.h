@@ -69,6 +69,18 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * two launches shrinks from 3.7 to 2.0 us; 4096^3 -4 %, 8192 x 16384 x 256 -8 %, 16384^2 x 256 +1.5 %: the tuner decides
  * per shape.  Results are bit-identical either way. */
 #define HGEMM_PLAN_NT_STORE 0x20000
+/* Plan flag: STREAM-K (the reference's H100 tree: cutlass::gemm::StreamKScheduler, kernels/h100_F32F16F16F32/
+ * 128_4096_16384.cu:79, 16384_512_2048.cu:71-73).  One persistent launch: the tiles x K-stages of the GEMM form one
+ * tile-major sequence and each of G workgroups walks a contiguous run of it, so the chip is filled whatever the tile count
+ * (12288 x 128 x 8192: 96 tiles of 128 x 128 on 256 CUs) and the workgroups of a cut tile start their K walks at different
+ * offsets.  With the flag the low 16 bits of `splits` are G (0 or 1: one resident wave of workgroups, 256 x the geometry's
+ * workgroups per CU).  At most the first and the last segment of a run are partial tiles; they go through compact fp32
+ * slabs and per-tile arrival counters, the workgroup that completes a tile adds its parts in K order (deterministic, nobody
+ * waits).  Geometries of the classic ("t") and register-staged ("r") families have the kernel
+ * (hgemm_mi355x_config_streamk); elsewhere, or without workspace, the plan runs as the geometry's plain launch.
+ * HGEMM_PLAN_NT_STORE is honoured by the direct fp16 epilogues (every family, whole tiles of a stream-K run included); the
+ * two-pass combine kernel and the any-shape kernels ignore it. */
+#define HGEMM_PLAN_STREAMK 0x40000
 
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)
@@ -122,6 +134,8 @@ int hgemm_mi355x_config_by_name(const char* name);
  * returns HGEMM_ERR_BAD_ARG for a table geometry when K is not a multiple (the planner never picks one); 1 for
  * the special ids. */
 int hgemm_mi355x_config_k_granularity(int config_id);
+/* > 0 when the geometry has a stream-K kernel (HGEMM_PLAN_STREAMK): workgroups of it one CU holds. */
+int hgemm_mi355x_config_streamk(int config_id);
 
 /* Split-K workspace.  Default: the library keeps one private device buffer per (device, stream) pair that
  * issued a split-K plan and grows it on first use of a bigger plan only (never in steady state; growing

@@ -242,35 +242,56 @@ def hybrid_partition(tiles: int, ksteps: int, G: int):
     return tiles - tail, tail, S, per
 
 
+def streamk_min_steps(kgran: int) -> int:
+    """hgemm_api.hip: streamk_min_steps -- stages closer than this to a tile boundary are not worth a cut."""
+    return 2 if kgran >= 256 else 3 if kgran >= 128 else 4
+
+
+def streamk_start(tiles: int, ksteps: int, G: int, min_steps: int, w: int) -> int:
+    """First stage of workgroup w's run: hgemm_kernel.hpp sk_start() restated (the device closed form).
+    base(w) = w * q + min(w, r) with tiles * ksteps = q * G + r; a boundary closer than min_steps to a tile boundary snaps
+    onto it; a tile with fewer than 2 * min_steps stages is never cut (the boundary goes to the nearer end)."""
+    total = tiles * ksteps
+    if w <= 0:
+        return 0
+    if w >= G:
+        return total
+    q, r = divmod(total, G)
+    x = w * q + min(w, r)
+    rem = x % ksteps
+    if ksteps < 2 * min_steps:
+        x += -rem if rem * 2 < ksteps else ksteps - rem
+    elif rem < min_steps:
+        x -= rem
+    elif ksteps - rem < min_steps:
+        x += ksteps - rem
+    return x
+
+
+def streamk_owner(tiles: int, ksteps: int, G: int, min_steps: int, x: int) -> int:
+    """sk_owner(): the LAST workgroup whose run starts at or before stage x (binary search, as on the device)."""
+    lo, hi = 0, G
+    while hi - lo > 1:
+        mid = (lo + hi) >> 1
+        if streamk_start(tiles, ksteps, G, min_steps, mid) <= x:
+            lo = mid
+        else:
+            hi = mid
+    return lo
+
+
 def streamk_partition(tiles: int, ksteps: int, G: int, min_steps: int = 4):
-    """Design model of the stream-K schedule planned for round 4 (what every hipBLASLt kernel on
-    this chip runs).  The tiles x ksteps K-steps of a GEMM form one sequence, tile-major; workgroup w of G takes the contiguous
-    run [start(w), start(w + 1)), start(w) = w * total // G, with a run boundary that falls within `min_steps` of a tile
-    boundary snapped onto it (a segment shorter than the pipeline prologue costs more than the imbalance it removes).
+    """The stream-K schedule of hgemm_tn_sk_kernel / hgemm_tn_rs_sk_kernel (hgemm_kernel.hpp: StreamK; what every hipBLASLt
+    kernel on this chip runs, and the reference's H100 StreamKScheduler shapes).  The tiles x ksteps pipeline stages of a GEMM
+    form one sequence, tile-major; workgroup w of G takes the contiguous run [start(w), start(w + 1)) (streamk_start).
     -> list over workgroups of segments (tile, k0, k1, slot): slot = 0 when the segment opens the workgroup's run, 1 otherwise,
     None for a segment that covers its whole tile (stored directly, no slab).  A workgroup has at most two partial segments
-    (its first and its last), so 2 * G compact slabs suffice; the parts of a tile are consecutive workgroups in K order, the
-    one that draws the last ticket of the tile's arrival counter adds the slabs in workgroup order (deterministic, like the
-    single-launch split-K of today, whose (split, tile) items are the special case of equal parts)."""
-    total = tiles * ksteps
-    # no more workgroups than runs of min_steps; a tile shorter than two prologues is never cut (plain data-parallel walk)
-    ge = max(1, min(G, total // min_steps if ksteps >= 2 * min_steps else tiles))
-    starts = []
-    for w in range(G + 1):
-        x = min(w, ge) * total // ge
-        r = x % ksteps
-        if ksteps < 2 * min_steps:
-            x -= r if r * 2 < ksteps else r - ksteps
-        elif 0 < r < min_steps:
-            x -= r
-        elif ksteps - min_steps < r < ksteps:
-            x += ksteps - r
-        starts.append(min(x, total))
-    for w in range(1, G + 1):                       # snapping must keep the starts monotonic
-        starts[w] = max(starts[w], starts[w - 1])
+    (its first and its last), so 2 * G compact slabs suffice (slab id 2 * w + slot); the parts of a tile are consecutive
+    workgroups in K order, the one that completes the tile's stage count adds the slabs in workgroup order (deterministic)."""
     out = []
     for w in range(G):
-        a, b = starts[w], starts[w + 1]
+        a, b = streamk_start(tiles, ksteps, G, min_steps, w), streamk_start(tiles, ksteps, G, min_steps, w + 1)
+        assert a <= b
         segs = []
         x = a
         while x < b:
@@ -281,6 +302,22 @@ def streamk_partition(tiles: int, ksteps: int, G: int, min_steps: int = 4):
             x += k1 - k0
         out.append(segs)
     return out
+
+
+def streamk_combine_parts(tiles: int, ksteps: int, G: int, min_steps: int, tile: int):
+    """sk_epilogue()'s enumeration of a cut tile's parts: -> [(slab id, k0, k1)] in K order, found from the tile id alone."""
+    t0, t1 = tile * ksteps, (tile + 1) * ksteps
+    parts = []
+    w = streamk_owner(tiles, ksteps, G, min_steps, t0)
+    while w < G:
+        b, e = streamk_start(tiles, ksteps, G, min_steps, w), streamk_start(tiles, ksteps, G, min_steps, w + 1)
+        if b >= t1:
+            break
+        lo, hi = max(b, t0), min(e, t1)
+        if hi > lo:
+            parts.append((2 * w + (0 if b >= t0 else 1), lo - t0, hi - t0))
+        w += 1
+    return parts
 
 
 def tail_item(bid: int, tail_first: int, tail_tiles: int, per: int, ksteps: int):

@@ -72,11 +72,92 @@ def test_every_geometry_and_split_k_is_exact(g, oracle):
     a, b = oracle.zero_one_inputs(m, n, k, rng)
     truth = oracle.truth_numpy(a, b)
     TWO_PASS = 0x10000   # HGEMM_SPLITK_FUSED: single-launch split-K; plain counts = slabs + combine kernel
+    SK = 0x40000         # HGEMM_PLAN_STREAMK | persistent workgroups (0: one resident wave); ignored by families without the kernel
     for cid, name in enumerate(g.config_names()):
-        for splits, group in [(1, 1), (1, 3), (2, 1), (5, 1), (16, 2), (2 | TWO_PASS, 1), (5 | TWO_PASS, 1), (16 | TWO_PASS, 2)]:
+        for splits, group in [(1, 1), (1, 3), (2, 1), (5, 1), (16, 2), (2 | TWO_PASS, 1), (5 | TWO_PASS, 1), (16 | TWO_PASS, 2),
+                              (SK, 1), (SK | 7, 3), (SK | 31, 1), (SK | 90, 2)]:
             for _ in range(2 if splits > 1 else 1):   # twice: the per-tile arrival counters must be back at zero
                 got = g.gemm(a, b, plan=(cid, splits, group))
                 assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, splits, group)
+
+
+STREAMK_CASES = [  # (config, workgroups, group, (M, N, K)): grids that cut tiles at odd stages, several segments per run, ragged edges
+    ("r128x128_k128", 256, 4, (1536, 128, 8192)),       # 12 tiles x 64 stages on 256 workgroups: every tile has ~21 parts
+    ("r128x128_k128", 37, 1, (1100, 300, 2048)),        # ragged M and N edges, 27 tiles x 16 stages over 37 workgroups
+    ("r64x64_k256", 512, 8, (2048, 64, 8192)),          # two workgroups per CU, BKS = 256
+    ("r96x128_k128", 200, 2, (1536, 256, 4096)),        # 96-row member
+    ("r64x128_k128", 0, 4, (192, 4000, 2048)),          # default grid, ragged N
+    ("t128x64_w4x2_m16_s4", 256, 4, (512, 4096, 4096)), # 256 tiles on 256 workgroups: nothing is cut (persistent data-parallel walk)
+    ("t128x64_w4x2_m16_s4", 200, 4, (512, 4096, 4096)), # ... 1.28 tiles per workgroup
+    ("t128x128_w2x2_m16_s3", 256, 8, (3072, 3072, 1024)),  # 576 tiles x 16 stages: 36 stages per workgroup = 2.25 tiles
+    ("t64x128_w2x4_m16_s3", 512, 2, (1000, 1096, 2056)),   # ragged edges and a partial last stage (K % 64 = 8)
+    ("t256x128_w4x2_m16_s2", 100, 2, (2048, 2048, 832)),   # 128 tiles x 13 stages over 100 workgroups
+    ("t32x32_w1x1_m16_s4", 1024, 4, (96, 160, 16384)),     # 15 tiny tiles x 256 stages: every tile has ~68 parts
+    ("t128x128_w2x2_m32_s2", 300, 1, (1152, 1152, 4096)),  # 32x32x16 MFMA accumulators through the slabs
+]
+
+
+@pytest.mark.parametrize("case", STREAMK_CASES, ids=lambda c: f"{c[0]}-G{c[1]}-{'x'.join(map(str, c[3]))}")
+def test_stream_k_is_exact_and_deterministic(g, oracle, case):
+    """Stream-K (HGEMM_PLAN_STREAMK; the reference's H100 StreamKScheduler shapes, kernels/h100_F32F16F16F32/128_4096_16384.cu:79):
+    0/1 inputs bit-exact against the oracle, twice (the arrival counters must return to zero), and N(0,1) inputs within
+    tolerance and bit-identical over repeats (the parts of a tile are added in K order, whoever completes it)."""
+    cfg, wgs, group, (m, n, k) = case
+    L = g.lib()
+    cid = g.config_names().index(cfg)
+    assert L.hgemm_mi355x_config_streamk(cid) > 0
+    rng = np.random.default_rng(m + 3 * n + 7 * k)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a, b)
+    for _ in range(2):
+        got = g.gemm(a, b, plan=(cid, 0x40000 | wgs, group))
+        assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), case
+    ar = torch.randn((m, k), dtype=torch.half, device="cuda")
+    br = torch.randn((k, n), dtype=torch.half, device="cuda")
+    btr = br.t().contiguous()
+    ref = ar.float() @ br.float()
+    first = None
+    for rep in range(12):
+        c = torch.full((m, n), float("nan"), dtype=torch.half, device="cuda")
+        assert L.hgemm_mi355x_launch(cid, 0x40000 | wgs, group, ar.data_ptr(), br.data_ptr(), btr.data_ptr(), c.data_ptr(), m, n, k, k, k, n,
+                                     g.stream()) == 0
+        torch.cuda.synchronize()
+        if first is None:
+            first = c
+            assert ((c.float() - ref).abs().max() / ref.abs().max()).item() <= REL_TOL, case
+        else:
+            assert torch.equal(first.view(torch.int16), c.view(torch.int16)), (case, rep)
+
+
+def test_stream_k_without_workspace_or_kernel_degrades_to_the_plain_launch(g, oracle):
+    """A stream-K plan on a family without the kernel, or with a lent workspace that is too small, runs the geometry's plain
+    launch: same result, no error."""
+    import ctypes
+
+    L = g.lib()
+    L.hgemm_mi355x_set_workspace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    names = g.config_names()
+    m, n, k = 640, 768, 1024
+    rng = np.random.default_rng(5)
+    a, b = oracle.zero_one_inputs(m, n, k, rng)
+    truth = oracle.truth_numpy(a, b)
+    got = g.gemm(a, b, plan=(names.index("q256x256_w2x2"), 0x40000 | 256, 2))
+    assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
+    small = torch.zeros(300 << 10, dtype=torch.uint8, device="cuda")          # counters + 44 KiB: no room for the slabs
+    assert L.hgemm_mi355x_set_workspace(ctypes_ptr(small), small.numel()) == 0
+    try:
+        got = g.gemm(a, b, plan=(names.index("t128x128_w2x2_m16_s3"), 0x40000 | 64, 2))
+        assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
+    finally:
+        assert L.hgemm_mi355x_set_workspace(None, 0) == 0
+    got = g.gemm(a, b, plan=(names.index("t128x128_w2x2_m16_s3"), 0x40000 | 64, 2))
+    assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
+
+
+def ctypes_ptr(t):
+    import ctypes
+
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def test_asymmetric_identity_catches_transposes(g):
@@ -598,6 +679,14 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("q256x192_w2x2", 2 | 0x10000, (1024, 1536, 4160)),# ... single-launch split-K, odd slice lengths
         ("r96x128_k128", 2 | 0x10000, (1536, 128, 4096)),  # 96-row streaming tile
         ("r64x96_k128", 1, (100, 1056, 2048)),             # 96-column streaming tile, ragged M
+        # stream-K (HGEMM_PLAN_STREAMK | workgroups): the slab + arrival-counter protocol under repetition
+        ("r128x128_k128", 0x40000 | 256, (1536, 128, 8192)),      # every tile cut into ~21 parts
+        ("r128x64_k128", 0x40000 | 200, (4100, 64, 4096)),        # ragged M edge, 65 tiles x 32 stages over 200 workgroups
+        ("r64x128_k128", 0x40000 | 512, (192, 4000, 2048)),       # ragged N edge, two workgroups per CU
+        ("t128x64_w4x2_m16_s4", 0x40000 | 200, (1000, 1096, 2048)),   # 8-wave tile, ragged edges, tiles cut at odd stages
+        ("t64x128_w2x4_m16_s3", 0x40000 | 512, (512, 4096, 4160)),    # 65 stages per tile (odd), two workgroups per CU
+        ("t128x128_w2x2_m16_s3", 0x40000 | 256, (3072, 3072, 1024)),  # 2.25 tiles per workgroup
+        ("t64x64_w2x2_m16_s4", 0x40000 | 768, (192, 320, 8192)),      # 15 tiles x 128 stages: ~51 parts per tile
     ]
     for cfg, splits, (m, n, k) in cases:
         cid = names.index(cfg)
@@ -608,7 +697,9 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         first = None
         for rep in range(50):
             c.fill_(float("nan"))
-            group = int(rng.choice([1, 2, 3, 4, 8, 16]))
+            # (a stream-K run cuts the tiles where the raster order puts them: the summation grouping is a function of the
+            # plan, raster group included, so those paths keep one group)
+            group = 4 if splits & 0x40000 else int(rng.choice([1, 2, 3, 4, 8, 16]))
             assert L.hgemm_mi355x_launch(cid, splits, group, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, k, k, n,
                                          g.stream()) == 0
             torch.cuda.synchronize()

@@ -515,3 +515,44 @@ def test_tuned_table_overrides_apply_in_order(tmp_path):
     assert list(per["64_64_64"]) == [("t32x64_w1x2_m16_s4", 1, 2)]        # the later override wins although it is the slowest
     assert list(per["128_128_128"]) == [("t32x64_w1x2_m16_s4", 1, 1)]     # only the first override knows this shape
 
+
+
+def test_stream_k_partition_in_the_library_is_the_model(lib):
+    """hgemm_kernel.hpp sk_start / sk_owner (what every producer and the combiner evaluate on the device, compiled for the host
+    here) against tests/kernel_layout_model.py: every run start and the owner of every tile's first stage."""
+    sys.path.insert(0, str(REPO / "tests"))
+    import kernel_layout_model as klm
+
+    f = lib.hgemm_mi355x_selfcheck_streamk
+    f.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)]
+    out = (ctypes.c_int * 2)()
+    for tiles, ksteps, G, mn in [(144, 48, 256, 4), (96, 64, 256, 3), (97, 33, 206, 3), (2304, 192, 512, 4), (255, 7, 256, 4),
+                                 (1, 256, 256, 2), (128, 128, 256, 3), (1000, 9, 768, 4), (4, 1000, 1024, 4), (65536, 16, 4096, 4)]:
+        for w in list(range(0, G + 1, max(1, G // 97))) + [G - 1, G]:
+            assert f(tiles, ksteps, G, mn, w, 0, out) == 0
+            assert out[0] == klm.streamk_start(tiles, ksteps, G, mn, w), (tiles, ksteps, G, mn, w)
+        for tile in range(0, tiles, max(1, tiles // 61)):
+            x = tile * ksteps
+            assert f(tiles, ksteps, G, mn, 0, x, out) == 0
+            assert out[1] == klm.streamk_owner(tiles, ksteps, G, mn, x)
+            b = klm.streamk_start(tiles, ksteps, G, mn, out[1])
+            e = klm.streamk_start(tiles, ksteps, G, mn, out[1] + 1)
+            assert b <= x < e
+    assert f(1 << 20, 1 << 12, 256, 4, 0, 0, out) != 0      # beyond 2^30 stages: rejected (the launch falls back)
+
+
+def test_stream_k_plans_are_priced_and_flags_are_not_split_counts(lib):
+    """hgemm_mi355x_model_us takes `splits` as the launch does (a row with HGEMM_PLAN_NT_STORE was priced as 131073
+    splits); stream-K plans have a finite estimate where the geometry has the kernel."""
+    lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    q = lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
+    assert lib.hgemm_mi355x_model_us(q, 1, 4096, 4096, 4096) == lib.hgemm_mi355x_model_us(q, 1 | 0x20000, 4096, 4096, 4096)
+    assert lib.hgemm_mi355x_model_us(q, 2 | 0x10000, 4096, 4096, 4096) == lib.hgemm_mi355x_model_us(q, 2, 4096, 4096, 4096)
+    assert lib.hgemm_mi355x_config_streamk(q) == 0
+    for name in (b"r128x128_k128", b"t128x64_w4x2_m16_s4", b"t128x128_w2x2_m16_s3", b"r64x64_k256"):
+        c = lib.hgemm_mi355x_config_by_name(name)
+        assert lib.hgemm_mi355x_config_streamk(c) >= 1
+        us = lib.hgemm_mi355x_model_us(c, 0x40000, 12288, 128, 8192)
+        assert 10.0 < us < 500.0
+    assert lib.hgemm_mi355x_config_streamk(lib.hgemm_mi355x_config_by_name(b"t256x256_w2x4_m16_s2")) == 0
+    assert lib.hgemm_mi355x_workspace_bytes(512, 512, 0x40000 | 256) >= (256 << 10) + 2 * 256 * 128 * 128 * 4

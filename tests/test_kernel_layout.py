@@ -274,14 +274,25 @@ def test_staged_epilogue_turns_mfma_tiles_into_full_rows():
     assert wconf <= 4 * 4          # four ds_write_b64, four lane groups each, one extra cycle (rows r and r + 8) at most
 
 
-@pytest.mark.parametrize("tiles,ksteps,G", [(144, 48, 256), (192, 128, 256), (96, 128, 256), (688, 64, 256), (2304, 192, 256), (18, 3, 256),
-                                            (257, 64, 256), (255, 7, 256), (1, 256, 256), (576, 96, 256), (300, 5, 256)])
-def test_stream_k_partition_design_covers_every_k_step_once_with_two_slabs_per_workgroup(tiles, ksteps, G):
-    """Round-4 design model (kernel_layout_model.streamk_partition): the invariants the device code will rely on."""
-    part = klm.streamk_partition(tiles, ksteps, G)
+SK_CASES = [(144, 48, 256, 4), (192, 128, 256, 3), (96, 64, 256, 3), (688, 64, 256, 4), (2304, 192, 256, 4), (18, 3, 256, 4),
+            (257, 64, 256, 4), (255, 7, 256, 4), (1, 256, 256, 2), (576, 96, 512, 4), (300, 5, 256, 4), (96, 64, 512, 3),
+            (128, 128, 256, 3), (97, 33, 206, 3), (4, 1000, 1024, 4), (1000, 9, 768, 4), (3, 8, 4, 4)]
+
+
+def _sk_grid(tiles, ksteps, G, mn):
+    """hgemm_mi355x_launch: no more workgroups than runs of min_steps stages"""
+    return max(1, min(G, max(1, tiles * ksteps // mn)))
+
+
+@pytest.mark.parametrize("tiles,ksteps,G,mn", SK_CASES)
+def test_stream_k_partition_covers_every_stage_once_with_two_slabs_per_workgroup(tiles, ksteps, G, mn):
+    """The stream-K schedule the device kernels run (kernel_layout_model.streamk_partition = hgemm_kernel.hpp sk_start): the
+    invariants the slab / arrival-counter protocol relies on."""
+    G = _sk_grid(tiles, ksteps, G, mn)
+    part = klm.streamk_partition(tiles, ksteps, G, mn)
     assert len(part) == G
     covered = {}
-    slabs = set()
+    slabs = {}
     for w, segs in enumerate(part):
         partial = [sg for sg in segs if sg[3] is not None]
         assert len(partial) <= 2 and len({sg[3] for sg in partial}) == len(partial)          # one slab per slot
@@ -293,19 +304,24 @@ def test_stream_k_partition_design_covers_every_k_step_once_with_two_slabs_per_w
                 assert (tile, k) not in covered
                 covered[(tile, k)] = w
             if slot is not None:
-                assert (w, slot) not in slabs
-                slabs.add((w, slot))
-                assert k1 - k0 >= 4 and ksteps >= 8                                            # no cut shorter than the prologue; short tiles stay whole
+                assert 2 * w + slot not in slabs
+                slabs[2 * w + slot] = (tile, k0, k1)
+                assert k1 - k0 >= mn and ksteps >= 2 * mn                                      # no cut shorter than the prologue; short tiles stay whole
     assert len(covered) == tiles * ksteps
     # the parts of a tile are consecutive workgroups in K order: the combine adds their slabs in workgroup order
     for tile in range(tiles):
         owners = [covered[(tile, k)] for k in range(ksteps)]
-        assert owners == sorted(owners) and set(owners) == set(range(owners[0], owners[-1] + 1))
+        assert owners == sorted(owners)
+    # the combiner finds exactly the producers' slabs of its tile, in K order, and their stage counts complete the tile
+    cut = sorted({t for (t, _, _) in slabs.values()})
+    for tile in cut:
+        parts = klm.streamk_combine_parts(tiles, ksteps, G, mn, tile)
+        want = sorted((k0, k1, sid) for sid, (t, k0, k1) in slabs.items() if t == tile)
+        assert [(k0, k1, sid) for sid, k0, k1 in parts] == want
+        assert sum(k1 - k0 for _, k0, k1 in parts) == ksteps and parts[0][1] == 0 and parts[-1][2] == ksteps
+        assert all(a[2] == b[1] for a, b in zip(parts, parts[1:]))
     # balance: nobody carries more than the even share plus the snapping distance
     loads = [sum(k1 - k0 for _, k0, k1, _ in segs) for segs in part]
-    active = [x for x in loads if x]
-    share = tiles * ksteps / len(active)
-    slack = 2 * 4 if ksteps >= 8 else ksteps
-    assert max(loads) <= share + slack + 1 and min(active) >= min(share - slack - 1, 4 if ksteps >= 8 else 1)
-    assert len(active) == G or tiles * ksteps < G * 8 or ksteps < 8
-
+    share = tiles * ksteps / G
+    slack = 2 * mn if ksteps >= 2 * mn else ksteps
+    assert max(loads) <= share + slack + 1
