@@ -198,6 +198,21 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   // family q sustain the classic rate per flop (their gain is the pipelining, modelled by step_lat), and q beats
   // s by a few percent once a work item has >= 16 K-steps, s wins below (one coordinate computation per item).
   // Regret of the model's pick among the measured candidates, ties broken in table order: 5.5 % (6.8 % before).
+  if (e.name[0] == 'w') {
+    // family "w" (wave-direct, no LDS staging): a trip of four K = 32 slices is one round trip to memory (~0.9 us cold, less once
+    // the rows stream), the "_k4" members walk K with four waves; MFMA and load issue are never what bounds these shapes
+    const bool k4 = e.wm * e.wn == 1;
+    const double trips = std::ceil((double)(K / splits) / 32.0 / (k4 ? 16.0 : 4.0));
+    const double main_w = rounds * (0.9 + 0.45 * std::max(0.0, trips - 1.0) + (k4 ? 0.25 : 0.0));
+    double bytes_w = 2.0 * ((double)M * K + (double)N * K + (double)M * N), extra_w = 0.0;
+    if (splits > 1) {
+      bytes_w += 8.0 * (double)M * N * splits;
+      extra_w = kBoundaryUs + 4.0 * (double)M * N * (splits + 0.5) / kHbmBytesUs + 0.17 * splits;
+    }
+    // every wave fetches its own fragments: L2 -> CU traffic is (BM + BN) rows per wave tile, not per workgroup tile
+    const double l2_bytes = 2.0 * (double)K * ((double)tiles_m * tiles_n) * (e.wm * e.wn) * (e.bm / e.wm + e.bn / e.wn) * (k4 ? 1.0 : 1.0);
+    return kLaunchUs - 0.7 + std::max(main_w, std::max(bytes_w / kHbmBytesUs, l2_bytes / 2.0e7)) + extra_w;
+  }
   const bool is_q = e.name[0] == 'q', is_q128 = is_q && e.bm == 128 && e.bn == 128;
   const char family = is_q ? 's' : e.name[0];   // 'q' = 's' with the early-A split
   const double reuse = (double)tm * tn / (tm + tn);
@@ -262,6 +277,8 @@ void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     if (e.bn > N * 2 && e.bn > 32) continue;
     if (!k_ok(e, K)) continue;
     if ((e.name[0] == 's' || e.name[0] == 'q') && e.mi == 32) continue;   // experimental 32x32x16 members: explicit plans only
+    // family "w" inside its domain only: a K of one or two pipeline steps, or a tiny output with a long K
+    if (e.name[0] == 'w' && !(K <= 128 || (long)M * N <= 128L * 128L)) continue;
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && ksteps / s < 4) break;
       const double t = model_us(e, M, N, K, s);

@@ -31,12 +31,21 @@ namespace hgemm_mi355x {
 #define HGEMM_RSINST_2(...)
 #define HGEMM_RSINST_3(...)
 #undef HGEMM_RSINST_0
-#define HGEMM_RSINST_0(BM, BN, BKS) \
-  template void launch_rs<CfgRS<BM, BN, BKS>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
-#define HGEMM_RS(G, BM, BN, BKS) HGEMM_RSINST_##G(BM, BN, BKS)
+#define HGEMM_RSINST_0(BM, BN, BKS, LB) \
+  template void launch_rs<CfgRS<BM, BN, BKS, LB>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_RS(G, BM, BN, BKS, LB) HGEMM_RSINST_##G(BM, BN, BKS, LB)
+#define HGEMM_WDINST_0(...)
+#define HGEMM_WDINST_1(...)
+#define HGEMM_WDINST_2(...)
+#define HGEMM_WDINST_3(...)
+#undef HGEMM_WDINST_0
+#define HGEMM_WDINST_0(FM, FN, KW) \
+  template void launch_wd<CfgWD<FM, FN, KW>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_WD(G, FM, FN, KW) HGEMM_WDINST_##G(FM, FN, KW)
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
 #undef HGEMM_RS
+#undef HGEMM_WD
 }  // namespace hgemm_mi355x

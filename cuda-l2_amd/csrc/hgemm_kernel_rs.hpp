@@ -23,16 +23,26 @@
 
 namespace hgemm_mi355x {
 
-template <int BM_, int BN_, int BKS_>
+// LB = LDS buffers: 1 (round 2) or 2 ("_d" members, round 4).  With one buffer a stage is two phases between barriers
+// (MFMAs on stage t | ds_write stage t+1, issue the loads of stage t+3): nothing of the CU's LDS-write, load-issue and MFMA time
+// overlaps, and on the N = 128 / M = 128 streaming shapes the sum of the three is what a stage takes (16384 x 128 x 16384 at
+// 3.9 TB/s where the N = 64 shapes, with half the MFMA and fragment work per streamed byte, reach 5.6-6.3).  With two buffers
+// stage t+1 is written to the OTHER buffer while stage t is computed: one barrier per stage, and the ds_writes, the global
+// loads of stage t+3 and the MFMAs of stage t are one basic block the hardware overlaps.
+template <int BM_, int BN_, int BKS_, int LB_ = 1>
 struct CfgRS : Cfg<BM_, BN_, 2, 2, 16, 2> {
   using Base = Cfg<BM_, BN_, 2, 2, 16, 2>;
+  static constexpr int LB  = LB_;
   static constexpr int BKS = BKS_;                        // K halfs per stage
   static constexpr int RB  = BKS * 2;                     // LDS row bytes
   static constexpr int NCH = RB / 16;                     // 16-byte chunks per row
   static constexpr int KS  = BKS / 32;                    // MFMA K=32 slices per stage
   static constexpr int CA  = BM_ * NCH / Base::THREADS;   // chunks per thread per stage, A / B
   static constexpr int CB  = BN_ * NCH / Base::THREADS;
-  static constexpr int LDS_BYTES = (BM_ + BN_) * RB;      // ONE buffer
+  static constexpr int STAGE_BYTES = (BM_ + BN_) * RB;
+  static constexpr int LDS_BYTES = LB_ * STAGE_BYTES;
+  static constexpr int WGS_PER_CU = (BM_ * BN_ <= 64 * 128 && LDS_BYTES <= 64 * 1024) ? 2 : 1;   // two wherever tile and LDS allow it
+  static_assert(LB_ == 1 || LB_ == 2, "one or two LDS buffers");
   static_assert(BKS == 128 || BKS == 256, "stage depth");
   static_assert((BM_ * NCH) % Base::THREADS == 0 && (BN_ * NCH) % Base::THREADS == 0, "whole chunks per thread");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -163,18 +173,20 @@ __device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, i
     if (nt_b) { _Pragma("unroll") for (int p = 0; p < CB; ++p) RBV[p] = RS_LD1(rsB, voff_b + p * step_b, kb_, true); }  \
     else      { _Pragma("unroll") for (int p = 0; p < CB; ++p) RBV[p] = RS_LD1(rsB, voff_b + p * step_b, kb_, false); } \
   } while (0)
-#define RS_WRITE(RA, RBV)                                                                           \
+#define RS_WRITE_TO(BUF, RA, RBV)                                                                   \
   do {                                                                                              \
-    _Pragma("unroll") for (int p = 0; p < CA; ++p) *(f16x8*)(smem + lds_of(p)) = RA[p];             \
-    _Pragma("unroll") for (int p = 0; p < CB; ++p) *(f16x8*)(smem + BM * RB + lds_of(p)) = RBV[p];  \
+    _Pragma("unroll") for (int p = 0; p < CA; ++p) *(f16x8*)((BUF) + lds_of(p)) = RA[p];            \
+    _Pragma("unroll") for (int p = 0; p < CB; ++p) *(f16x8*)((BUF) + BM * RB + lds_of(p)) = RBV[p]; \
   } while (0)
-#define RS_COMPUTE()                                                                                \
+#define RS_WRITE(RA, RBV) RS_WRITE_TO(smem, RA, RBV)
+#define RS_COMPUTE() RS_COMPUTE_FROM(smem)
+#define RS_COMPUTE_FROM(BUF)                                                                        \
   do {                                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                             \
       const int fo = frag_lane ^ (ks << 6);                                                         \
       f16x8 af[FM], bf[FN];                                                                         \
-      _Pragma("unroll") for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(smem + a_row_base + i * 16 * RB + fo); \
-      _Pragma("unroll") for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(smem + b_row_base + j * 16 * RB + fo); \
+      _Pragma("unroll") for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)((BUF) + a_row_base + i * 16 * RB + fo); \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)((BUF) + b_row_base + j * 16 * RB + fo); \
       _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                \
         _Pragma("unroll") for (int j = 0; j < FN; ++j)                                              \
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);     \
@@ -192,6 +204,34 @@ __device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, i
   __syncthreads();
   // invariant at the top of step t (t even): LDS = stage t, ra1/rb1 = stage t+1, ra0/rb0 = stage t+2 (in flight)
   int t = 0;
+  if constexpr (CFG::LB == 2) {
+    // two LDS buffers: stage t lives in buffer t & 1.  Step t writes stage t+1 into the other buffer (last read by the MFMAs of
+    // stage t-1, which every wave finished in front of the barrier that closed step t-1), refills its registers with stage
+    // t+3 and computes stage t; ONE barrier per stage makes stage t+1 visible and retires the reads of stage t.
+    char* const buf0 = smem;
+    char* const buf1 = smem + CFG::STAGE_BYTES;
+    for (; t + 4 < nk; t += 2) {           // stages t+3 and t+4 exist: every load is real
+      RS_WRITE_TO(buf1, ra1, rb1);         // stage t+1
+      RS_LOAD(ra1, rb1, t + 3);
+      RS_COMPUTE_FROM(buf0);               // stage t
+      __syncthreads();
+      RS_WRITE_TO(buf0, ra0, rb0);         // stage t+2
+      RS_LOAD(ra0, rb0, t + 4);
+      RS_COMPUTE_FROM(buf1);               // stage t+1
+      __syncthreads();
+    }
+    for (; t + 1 < nk; t += 2) {           // the last (up to four) stages
+      RS_WRITE_TO(buf1, ra1, rb1);
+      if (t + 3 < nk) RS_LOAD(ra1, rb1, t + 3);
+      RS_COMPUTE_FROM(buf0);
+      __syncthreads();
+      if (t + 2 < nk) RS_WRITE_TO(buf0, ra0, rb0);
+      RS_COMPUTE_FROM(buf1);
+      if (t + 2 < nk) __syncthreads();
+    }
+    if (t < nk) RS_COMPUTE_FROM(buf0);     // odd stage count: the last stage sits in buffer 0 (t is even)
+    return;
+  }
   // main loop: stages t+3 and t+4 exist, every load is real
   for (; t + 4 < nk; t += 2) {
     RS_COMPUTE();
@@ -225,12 +265,14 @@ __device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, i
 #undef RS_STAGE
 #undef RS_WRITE
 #undef RS_COMPUTE
+#undef RS_WRITE_TO
+#undef RS_COMPUTE_FROM
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <class CFG, int EPI>
 // two workgroups per CU wherever the tile allows it (second argument = waves per SIMD: <= 256 registers)
-__global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) ? 2 : 1) hgemm_tn_rs_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(CFG::THREADS, CFG::WGS_PER_CU) hgemm_tn_rs_kernel(const GemmArgs g) {
   prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, BKS = CFG::BKS;
@@ -257,7 +299,7 @@ __global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) 
 // Stream-K on family r (hgemm_kernel.hpp: StreamK): the skinny streaming shapes get their exact chip fill (12288 x 128 x 8192:
 // 96 tiles of 128 x 128 on 256 CUs) and every workgroup of a cut tile starts its K walk somewhere else.
 template <class CFG>
-__global__ void __launch_bounds__(CFG::THREADS, (CFG::BM * CFG::BN <= 64 * 128) ? 2 : 1) hgemm_tn_rs_sk_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(CFG::THREADS, CFG::WGS_PER_CU) hgemm_tn_rs_sk_kernel(const GemmArgs g) {
   prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, BKS = CFG::BKS;

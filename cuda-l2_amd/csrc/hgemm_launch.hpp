@@ -2,6 +2,7 @@
 #pragma once
 #include "hgemm_kernel_rs.hpp"
 #include "hgemm_kernel_sq.hpp"
+#include "hgemm_kernel_wd.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -88,6 +89,16 @@ void launch_rs(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
     HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
   else
     HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_C16>), grid, CFG::THREADS, stream, ts, g);
+}
+
+template <class CFG>
+void launch_wd(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_wd_kernel<CFG, EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
+    HGEMM_LAUNCH((hgemm_tn_wd_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
+  else
+    HGEMM_LAUNCH((hgemm_tn_wd_kernel<CFG, EPI_C16>), grid, CFG::THREADS, stream, ts, g);
 }
 
 struct KernelEntry {

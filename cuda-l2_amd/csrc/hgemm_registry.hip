@@ -3,6 +3,7 @@
 #include "hgemm_kernel_rg.hpp"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace hgemm_mi355x {
 
@@ -12,13 +13,16 @@ namespace hgemm_mi355x {
   extern template void launch_sp<CfgSP<BM, BN, WM, WN, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI) \
   extern template void launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
-#define HGEMM_RS(G, BM, BN, BKS) \
-  extern template void launch_rs<CfgRS<BM, BN, BKS>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_RS(G, BM, BN, BKS, LB) \
+  extern template void launch_rs<CfgRS<BM, BN, BKS, LB>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
+#define HGEMM_WD(G, FM, FN, KW) \
+  extern template void launch_wd<CfgWD<FM, FN, KW>>(const GemmArgs&, int, hipStream_t, int, TimingSlot);
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
 #undef HGEMM_RS
+#undef HGEMM_WD
 
 // The table holds host function pointers: keep it out of the device pass.
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -30,6 +34,13 @@ constexpr int sk_residency(int lds_bytes, int nw, int acc_regs) {
   const int r = by_lds < by_waves ? (by_lds < by_regs ? by_lds : by_regs) : (by_waves < by_regs ? by_waves : by_regs);
   return acc_regs * 64 * nw > 256 * 128 ? 0 : r < 1 ? 1 : r > 4 ? 4 : r;   // (no stream-K kernel beyond 256 x 128: hgemm_launch.hpp)
 }
+// "w<BM>x<BN>[_k4]" with the workgroup tile computed from the template arguments (static storage per instantiation)
+template <int BM, int BN, int KW>
+const char* wd_name() {
+  static char buf[24];
+  if (!buf[0]) snprintf(buf, sizeof buf, "w%dx%d%s", BM, BN, KW == 4 ? "_k4" : "");
+  return buf;
+}
 #define HGEMM_STR2(x) #x
 #define HGEMM_STR(x) HGEMM_STR2(x)
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)                                                    \
@@ -40,14 +51,15 @@ constexpr int sk_residency(int lds_bytes, int nw, int acc_regs) {
    sk_residency(Cfg<BM, BN, WM, WN, MI, NB>::LDS_BYTES + 64, Cfg<BM, BN, WM, WN, MI, NB>::NW, BM * BN / (64 * Cfg<BM, BN, WM, WN, MI, NB>::NW))},
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)
-#define HGEMM_RS(G, BM, BN, BKS)
+#define HGEMM_RS(G, BM, BN, BKS, LB)
+#define HGEMM_WD(G, FM, FN, KW)
 const KernelEntry g_kernel_table[] = {
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
 #undef HGEMM_RS
-#define HGEMM_RS(G, BM, BN, BKS)
+#define HGEMM_RS(G, BM, BN, BKS, LB)
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
 // MI = 16 members keep their round-1 names (tuned tables refer to plans by name); MI = 32 members add "_m32"
 #define HGEMM_SP_NAME_16(BM, BN, WM, WN) "s" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN)
@@ -71,15 +83,27 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_CFG(G, BM, BN, WM, WN, MI, NB)
 #define HGEMM_SP(G, BM, BN, WM, WN, MI)
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)
-#define HGEMM_RS(G, BM, BN, BKS)                                                                            \
-  {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS), BM, BN, 2, 2, 16, 1, CfgRS<BM, BN, BKS>::THREADS,  \
-   CfgRS<BM, BN, BKS>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS>>, 0, true, BKS, false, (BM * BN <= 64 * 128) ? 2 : 1},
+#define HGEMM_RS_SUFFIX_1 ""
+#define HGEMM_RS_SUFFIX_2 "_d"
+#define HGEMM_RS(G, BM, BN, BKS, LB)                                                                                   \
+  {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS) HGEMM_RS_SUFFIX_##LB, BM, BN, 2, 2, 16, LB, CfgRS<BM, BN, BKS, LB>::THREADS, \
+   CfgRS<BM, BN, BKS, LB>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS, LB>>, 0, true, BKS, false, CfgRS<BM, BN, BKS, LB>::WGS_PER_CU},
+#include "hgemm_configs.def"
+#undef HGEMM_RS
+#undef HGEMM_WD
+#define HGEMM_RS(G, BM, BN, BKS, LB)
+// family "w": named by its WORKGROUP tile; "_k4" = the four waves split the K walk of one wave tile.  (K granularity 64: a
+// split-K chunk is then a whole number of K = 32 slices whatever the split count.)
+#define HGEMM_WD(G, FM, FN, KW)                                                                                          \
+  {wd_name<CfgWD<FM, FN, KW>::BM, CfgWD<FM, FN, KW>::BN, KW>(), CfgWD<FM, FN, KW>::BM, CfgWD<FM, FN, KW>::BN, CfgWD<FM, FN, KW>::WM, \
+   CfgWD<FM, FN, KW>::WN, 16, 1, CfgWD<FM, FN, KW>::THREADS, CfgWD<FM, FN, KW>::LDS_BYTES, &launch_wd<CfgWD<FM, FN, KW>>, 0, true, 64, false, 0},
 #include "hgemm_configs.def"
 };
 #undef HGEMM_CFG
 #undef HGEMM_SP
 #undef HGEMM_SQ
 #undef HGEMM_RS
+#undef HGEMM_WD
 const int g_num_kernels = (int)(sizeof(g_kernel_table) / sizeof(g_kernel_table[0]));
 #endif  // !__HIP_DEVICE_COMPILE__
 

@@ -154,34 +154,86 @@ def _vgprs(tok: str, bank: str = "v") -> set:
     return {base + int(m.group(1))} if m else set()
 
 
+def _audit_step(recent, code, bad):
+    """One instruction of the hazard scan: `recent` = [(registers written, wait states since, text)] of the VALU writes younger
+    than two wait states; returns the list behind this instruction."""
+    ops = code.replace(",", " ").split()
+    mn = ops[0]
+    if mn.startswith("v_mfma"):
+        src = set()
+        for tok in ops[2:4]:
+            src |= _vgprs(tok)
+        if len(ops) > 4:
+            src |= _vgprs(ops[4], "a")        # the accumulator input: v_accvgpr_write (the clears) is a VALU write, too
+        bad += [(txt, code) for (w, age, txt) in recent if age < 2 and w & src]
+        return [(w, age + 1, t) for (w, age, t) in recent if age + 1 < 2]
+    step = int(ops[1]) + 1 if mn == "s_nop" else 1
+    recent = [(w, age + step, t) for (w, age, t) in recent if age + step < 2]
+    if mn.startswith("v_") and not mn.startswith("v_cmp") and len(ops) > 1:
+        w = _vgprs(ops[1]) | _vgprs(ops[1], "a")
+        if w:
+            recent.append((frozenset(w), 0, code))
+    return recent
+
+
 def valu_to_mfma_source_hazards(lines):
     """(VALU line, MFMA line) pairs where an MFMA reads a VGPR as A / B operand fewer than two wait states behind a VALU write of
     it.  hipcc's hazard recognizer pads its own MFMAs for this; the persistent families write theirs as asm statements, which
     it does not see -- the MFMA would read the OLD register value.  (ds_read results are ordered by lgkmcnt, not by wait
-    states, and are not VALU writes.)"""
-    recent, bad = [], []          # recent: (registers written, wait states since, text)
+    states, and are not VALU writes.)
+    The scan follows the CONTROL FLOW (the 192 x 192 bug sat at a control-flow merge, and a straight-line scan only
+    sees textual fall-through): the stream is cut into basic blocks at labels and behind branches; a block is entered with the
+    union of the young VALU writes at the end of ALL its predecessors -- the block above it unless that ends in s_branch /
+    s_endpgm, and every block that branches to its label, loop back-edges included -- iterated to a fixpoint (a block shorter
+    than two wait states passes its own entry state on).  A branch counts as one wait state whether taken or not
+    (conservative: a taken branch refills the instruction buffer)."""
+    blocks, cur = [], {"label": None, "code": []}
     for ln in lines:
         code = ln.split(";")[0].strip()
-        if not code or code.endswith(":") or code.startswith((".", "#")):
+        if not code or code.startswith("#") or (code.startswith(".") and not code.endswith(":")):
             continue
-        ops = code.replace(",", " ").split()
-        mn = ops[0]
-        if mn.startswith("v_mfma"):
-            src = set()
-            for tok in ops[2:4]:
-                src |= _vgprs(tok)
-            if len(ops) > 4:
-                src |= _vgprs(ops[4], "a")        # the accumulator input: v_accvgpr_write (the clears) is a VALU write, too
-            bad += [(txt, code) for (w, age, txt) in recent if age < 2 and w & src]
-            recent = [(w, age + 1, t) for (w, age, t) in recent if age + 1 < 2]
+        if code.endswith(":"):
+            if cur["code"] or cur["label"] is not None:
+                blocks.append(cur)
+            cur = {"label": code[:-1], "code": []}
             continue
-        step = int(ops[1]) + 1 if mn == "s_nop" else 1
-        recent = [(w, age + step, t) for (w, age, t) in recent if age + step < 2]
-        if mn.startswith("v_") and not mn.startswith("v_cmp") and len(ops) > 1:
-            w = _vgprs(ops[1]) | _vgprs(ops[1], "a")
-            if w:
-                recent.append((w, 0, code))
-    return bad
+        cur["code"].append(code)
+        if re.match(r"s_(branch|cbranch_\w+|endpgm|setpc_b64|trap)\b", code):
+            blocks.append(cur)
+            cur = {"label": None, "code": []}
+    if cur["code"] or cur["label"] is not None:
+        blocks.append(cur)
+    index = {b["label"]: i for i, b in enumerate(blocks) if b["label"] is not None}
+    preds = [set() for _ in blocks]
+    for i, b in enumerate(blocks):
+        last = b["code"][-1] if b["code"] else ""
+        m = re.match(r"s_(branch|cbranch_\w+)\s+(\S+)", last)
+        if m and m.group(2) in index:
+            preds[index[m.group(2)]].add(i)
+        if i + 1 < len(blocks) and not re.match(r"s_(branch|endpgm|setpc_b64)\b", last):
+            preds[i + 1].add(i)
+    entry = [frozenset() for _ in blocks]
+    exits = [frozenset() for _ in blocks]
+    bad = []
+    for _ in range(8):                      # ages are < 2: the state space is tiny, two or three sweeps reach the fixpoint
+        changed = False
+        bad = []
+        for i, b in enumerate(blocks):
+            recent = sorted(entry[i], key=str)
+            for code in b["code"]:
+                recent = _audit_step(recent, code, bad)
+            out = frozenset(recent)
+            if out != exits[i]:
+                exits[i], changed = out, True
+        for i in range(len(blocks)):
+            e = frozenset().union(*[exits[p] for p in preds[i]]) if preds[i] else frozenset()
+            if e != entry[i]:
+                entry[i], changed = e, True
+        if not changed:
+            break
+    else:
+        raise AssertionError("hazard scan did not reach a fixpoint")
+    return sorted(set(bad))
 
 
 def test_no_valu_write_sits_within_two_wait_states_of_an_asm_mfma_that_reads_it(sp_functions):
@@ -211,3 +263,31 @@ def test_the_hazard_audit_catches_the_pattern():
     assert not valu_to_mfma_source_hazards([stream[1], "s_add_u32 m0, m0, 0x1000", "s_nop 0", stream[2]])   # two
     assert len(valu_to_mfma_source_hazards(["v_accvgpr_write_b32 a121, 0", stream[2]])) == 1  # a cleared accumulator read as SrcC
     assert not valu_to_mfma_source_hazards(["v_accvgpr_write_b32 a124, 0", stream[2]])
+
+
+def test_the_hazard_audit_follows_branches():
+    """Edges other than fall-through: a VALU write at the end of a block that JUMPS to a block opening with an asm MFMA,
+    a loop back-edge, and a merge where only one predecessor carries the write."""
+    mfma = "v_mfma_f32_16x16x32_f16 a[120:123], v[74:77], v[0:3], a[120:123]"
+    # taken branch: the write sits textually far away from the MFMA
+    taken = ["s_cmp_eq_u32 s0, 0", "s_cbranch_scc1 .LBB0_2", "v_perm_b32 v2, v9, v4, s68", "s_branch .LBB0_3",
+             ".LBB0_2:", "s_nop 4", "s_endpgm", ".LBB0_3:", mfma]
+    # (the branch is the one wait state between the write and the MFMA: still a hazard)
+    assert len(valu_to_mfma_source_hazards(taken)) == 1
+    assert not valu_to_mfma_source_hazards(taken[:-1] + ["s_nop 0", mfma])
+    # the same layout with the write in front of the OTHER exit is clean
+    other = ["s_cmp_eq_u32 s0, 0", "s_cbranch_scc1 .LBB0_2", "s_nop 0", "s_branch .LBB0_3",
+             ".LBB0_2:", "v_perm_b32 v2, v9, v4, s68", "s_endpgm", ".LBB0_3:", mfma]
+    assert not valu_to_mfma_source_hazards(other)
+    # loop back-edge: the write closes the loop body, the MFMA opens it
+    loop = ["s_mov_b32 s4, 8", ".LBB0_1:", mfma, "s_add_i32 s4, s4, -1", "s_cmp_lg_u32 s4, 0", "v_mov_b32 v1, v8", "s_cbranch_scc1 .LBB0_1", "s_nop 0"]
+    assert len(valu_to_mfma_source_hazards(loop)) == 1
+    assert not valu_to_mfma_source_hazards([ln for ln in loop if not ln.startswith("v_mov")])
+    # merge: fall-through predecessor is clean, the side entry is not
+    merge = ["s_cbranch_scc1 .LBB0_5", "s_nop 1", "s_branch .LBB0_6", ".LBB0_5:", "v_perm_b32 v3, v9, v4, s68", ".LBB0_6:", mfma]
+    assert len(valu_to_mfma_source_hazards(merge)) == 1
+    # a block shorter than two wait states hands its entry state on
+    short = ["v_perm_b32 v0, v9, v4, s68", "s_branch .LBB0_7", ".LBB0_7:", mfma]
+    assert len(valu_to_mfma_source_hazards(short)) == 1
+    short_ok = ["v_perm_b32 v0, v9, v4, s68", "s_branch .LBB0_7", ".LBB0_7:", "s_nop 0", mfma]
+    assert not valu_to_mfma_source_hazards(short_ok)

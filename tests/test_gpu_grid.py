@@ -44,3 +44,19 @@ def test_off_grid_shapes_are_exact_at_the_neighbour_planner_s_plans(tmp_path):
     recs = _run(tmp_path, "offgrid", ["--shape-file", str(shapes)])
     n = len([ln for ln in shapes.read_text().splitlines() if ln.strip() and not ln.startswith("#")])
     assert len(recs) == 2 * n and n >= 50
+
+
+def test_every_grid_shape_is_within_tolerance_on_normal_inputs(tmp_path):
+    """BASELINE.json north_star: "every shape must match torch.matmul within 1e-2 rel (fp16 acc) / 1e-3 rel (fp32 acc)".  All
+    1000 grid shapes x both entry points on N(0,1) operands, 1e-3 for both (CDNA4 accumulates in fp32 either way), reference
+    rows computed without the library (CPU fp32 / GPU fp64): tests/tools/verify_plans.py --randn."""
+    recs = _run(tmp_path, "grid_randn", ["--randn"])
+    assert len(recs) == 2000 and {r["run"] for r in recs} == {"fp32", "fp16"} and len({r["mnk"] for r in recs}) == 1000
+    assert all(r["relative_error"] <= 1e-3 and r["rows_checked"] >= min(128, int(r["mnk"].split("_")[0])) for r in recs)
+    assert {"cpu fp32", "gpu fp64"} == {r["reference"] for r in recs}
+
+
+def test_off_grid_shapes_are_within_tolerance_on_normal_inputs(tmp_path):
+    shapes = REPO / "cuda-l2_amd" / "tools" / "offgrid_shapes.txt"
+    recs = _run(tmp_path, "offgrid_randn", ["--randn", "--shape-file", str(shapes)])
+    assert len(recs) >= 100 and all(r["pass"] for r in recs)

@@ -160,6 +160,64 @@ def ctypes_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def test_special_values_round_like_the_reference(g):
+    """The epilogue's fp32 -> fp16 conversion and the non-finite / denormal paths, which 0/1 inputs (values <= 2047, exact in every
+    rounding mode) cannot see: the result must equal the reference's oracle expression (a.float() @ b.float()).half()
+    (zero_one_correctness_check.py:85-90) -- round-to-nearest-even incl. overflow to inf at 65520, ties to even at the bottom
+    of the denormal range, inf / NaN propagation (inf x 0, inf - inf), denormal operands and results -- for every kernel
+    family, both split-K forms (the slabs carry inf / NaN / denormals in fp32) and stream-K.  Every row's sum is exact in fp32
+    whatever the summation order."""
+    m, n, k = 128, 192, 512
+    a = torch.zeros((m, k), dtype=torch.half)
+    b = torch.zeros((k, n), dtype=torch.half)
+    b[0, :] = 1.0; b[1, :] = 1.0; b[300, :] = 1.0
+    b[0, 5::7] = 0.0                                  # columns where an inf in A meets a zero in B
+    b[2, :] = 2.0 ** -10
+    inf = float("inf")
+    a[0, 0] = 65504.0                                  # the largest finite value survives
+    a[1, 1] = 65504.0; a[1, 300] = 16.0                # 65520: the tie between 65504 and 2^16 rounds to even = inf
+    a[2, 0] = 65504.0; a[2, 300] = 8.0                 # 65512 rounds down to 65504
+    a[3, 0] = -65504.0; a[3, 1] = -16.0                # -inf
+    a[4, 0] = inf                                      # inf, and NaN where B has a zero
+    a[5, 1] = inf; a[5, 300] = -inf                    # inf - inf = NaN
+    a[6, 300] = float("nan")                           # NaN x anything
+    a[7, 1] = 2.0 ** -24                               # a denormal operand, a denormal result
+    a[8, 2] = 2.0 ** -14                               # 2^-14 x 2^-10 = 2^-24: a denormal result from normal operands
+    a[9, 2] = 2.0 ** -15                               # 2^-25: the tie between 0 and 2^-24 rounds to even = 0
+    a[10, 2] = 1.5 * 2.0 ** -15                        # 1.5 x 2^-25 rounds up to 2^-24
+    a[11, 1] = 1.0; a[11, 300] = 2.0 ** -11            # 1 + 2^-11: tie, rounds to even = 1
+    a[12, 1] = 1.0; a[12, 300] = 3 * 2.0 ** -11        # 1 + 3 x 2^-11: tie, rounds to even = 1 + 2^-9
+    a[13, 1] = 2048.0; a[13, 300] = 1.0                # 2049 -> 2048 (the first integer fp16 cannot hold)
+    a[14, 0] = 60000.0; a[14, 1] = 60000.0             # finite operands, overflowing sum
+    a[64:, :] = a[:64, :].clone()                      # the same rows in the second 64-row band of every tile
+    truth = (a.float() @ b.float()).half()
+    assert torch.isinf(truth[1]).all() and truth[2, 0] == 65504 and torch.isnan(truth[4, 5]) and truth[4, 0] == inf
+    assert truth[8, 0] == 2.0 ** -24 and truth[9, 0] == 0 and truth[10, 0] == 2.0 ** -24 and truth[11, 0] == 1 and truth[13, 0] == 2048
+    L = g.lib()
+    names = g.config_names()
+    ad, bd = a.cuda(), b.cuda()
+    btd = bd.t().contiguous()
+    plans = [("entry fp32", None), ("entry fp16", None), ("ragged", (-2, 1, 1)), ("generic", (-1, 1, 1))]
+    for cfg, splits in [("t64x64_w2x2_m16_s4", 1), ("t128x128_w2x2_m32_s2", 2), ("t128x128_w2x2_m16_s3", 2 | 0x10000), ("t64x64_w2x2_m16_s4", 0x40000 | 5),
+                        ("s256x128_w2x2", 2), ("q128x128_w2x2", 1), ("q256x256_w2x2", 1 | 0x20000), ("q128x256_w2x2", 2 | 0x10000), ("q192x256_w2x2", 1),
+                        ("q256x256_w2x2_m32", 1), ("r64x64_k256", 1), ("r128x64_k128", 2 | 0x10000), ("r128x128_k128", 0x40000 | 3)]:
+        plans.append((f"{cfg}/{splits:#x}", (names.index(cfg), splits, 1)))
+    for label, plan in plans:
+        c = torch.full((m, n), 7.0, dtype=torch.half, device="cuda")
+        if plan is None:
+            fn = L.hgemm_mi355x_fp16 if label.endswith("fp16") else L.hgemm_mi355x_fp32
+            st = fn(ad.data_ptr(), bd.data_ptr(), btd.data_ptr(), c.data_ptr(), m, n, k, g.stream())
+        else:
+            st = L.hgemm_mi355x_launch(plan[0], plan[1], plan[2], ad.data_ptr(), bd.data_ptr(), btd.data_ptr(), c.data_ptr(), m, n, k, k, k, n, g.stream())
+        assert st == 0, label
+        torch.cuda.synchronize()
+        got = c.cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(truth)), f"{label}: NaN pattern differs from the reference"
+        same = torch.where(torch.isnan(truth), torch.zeros_like(truth), truth).view(torch.int16) == torch.where(torch.isnan(got), torch.zeros_like(got), got).view(torch.int16)
+        bad = (~same).nonzero()
+        assert bad.numel() == 0, f"{label}: {bad.shape[0]} elements differ, first at {bad[0].tolist()}: got {got[tuple(bad[0])].item()} want {truth[tuple(bad[0])].item()}"
+
+
 def test_asymmetric_identity_catches_transposes(g):
     """A = I, B asymmetric: C must equal B bit for bit (an MFMA C-layout row/col swap would not)."""
     n = 512
@@ -687,6 +745,17 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("t64x128_w2x4_m16_s3", 0x40000 | 512, (512, 4096, 4160)),    # 65 stages per tile (odd), two workgroups per CU
         ("t128x128_w2x2_m16_s3", 0x40000 | 256, (3072, 3072, 1024)),  # 2.25 tiles per workgroup
         ("t64x64_w2x2_m16_s4", 0x40000 | 768, (192, 320, 8192)),      # 15 tiles x 128 stages: ~51 parts per tile
+        # family r with two LDS buffers ("_d": one barrier per stage) and family w (wave-direct, no LDS staging), round 4
+        ("r128x128_k128_d", 2 | 0x10000, (1536, 128, 4096)),      # single-launch split-K
+        ("r64x128_k128_d", 1, (192, 4000, 2048)),                 # ragged N edge
+        ("r128x64_k128_d", 3, (4100, 64, 4224)),                  # ragged M edge, two-pass split-K, 11 stages per slice
+        ("r64x64_k256_d", 0x40000 | 256, (2048, 64, 8192)),       # stream-K, BKS = 256
+        ("w64x64", 1, (64, 4096, 64)),                            # BASELINE config 1/2: one trip of two K slices
+        ("w32x128", 1, (1000, 520, 128)),                         # ragged edges, one trip of four slices
+        ("w128x32", 4, (520, 100, 1792)),                         # two-pass split-K, 14 slices per split (4 + 4 + 4 + 2)
+        ("w16x16_k4", 8 | 0x10000, (64, 64, 4096)),               # four waves per tile walk K, single-launch split-K on top
+        ("w32x32_k4", 2 | 0x10000, (100, 260, 2112)),             # ... ragged edges, 33 slices per split over four waves
+        ("w16x32_k4", 1, (48, 96, 1024)),                         # ... M = 48: one and a half tiles
     ]
     for cfg, splits, (m, n, k) in cases:
         cid = names.index(cfg)

@@ -61,7 +61,8 @@ def test_geometry_table(lib):
         info = (ctypes.c_int * 8)()
         assert lib.hgemm_mi355x_config_info(i, info) == 0
         bm, bn, wm, wn, mi, nbuf, threads, lds = list(info)
-        assert threads == wm * wn * 64 and threads % 64 == 0      # 64-wide waves
+        # 64-wide waves; the "_k4" members of family w put four waves on ONE wave tile (they split its K walk)
+        assert threads == wm * wn * 64 * (4 if name.endswith("_k4") else 1) and threads % 64 == 0
         assert lds <= 160 * 1024                                   # MI355X LDS per CU
         assert bm % (wm * mi) == 0 and bn % (wn * mi) == 0
         assert lib.hgemm_mi355x_config_by_name(name.encode()) == i
@@ -76,10 +77,13 @@ def test_planner_returns_a_valid_plan(lib, mnk):
     cfg, splits, group = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.hgemm_mi355x_plan(*mnk, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert 0 <= cfg.value < lib.hgemm_mi355x_num_configs()
-    count = splits.value & 0xFFFF          # | 0x10000 = HGEMM_SPLITK_FUSED (single-launch form), | 0x20000 = HGEMM_PLAN_NT_STORE
-    assert splits.value & ~0x3FFFF == 0
-    assert 1 <= count <= max(1, mnk[2] // 64) and group.value >= 1
-    assert lib.hgemm_mi355x_model_us(cfg.value, count, *mnk) > 0
+    count = splits.value & 0xFFFF          # | 0x10000 = HGEMM_SPLITK_FUSED (single-launch form), | 0x20000 = HGEMM_PLAN_NT_STORE,
+    assert splits.value & ~0x7FFFF == 0    # | 0x40000 = HGEMM_PLAN_STREAMK (the count is then the number of persistent workgroups)
+    if splits.value & 0x40000:
+        assert lib.hgemm_mi355x_config_streamk(cfg.value) > 0 and count <= 4096 and group.value >= 1
+    else:
+        assert 1 <= count <= max(1, mnk[2] // 64) and group.value >= 1
+    assert lib.hgemm_mi355x_model_us(cfg.value, splits.value, *mnk) > 0
     info = (ctypes.c_int * 8)()
     lib.hgemm_mi355x_config_info(cfg.value, info)
     assert info[0] <= 2 * max(mnk[0], 32) and info[1] <= 2 * max(mnk[1], 32)  # no tile that is mostly padding

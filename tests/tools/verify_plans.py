@@ -22,6 +22,17 @@ One operand pair per input class serves all shapes: the (M,N,K) problem is the t
 
 The second form checks the `--top` fastest candidates of every shape of a tuner result file with explicit
 plans; tools/make_tuned_table.py --verified only accepts plans that have an exact record there.
+
+  python tests/tools/verify_plans.py --randn --out cuda-l2_amd/tuning/r04_randn_1000.jsonl       # N(0,1) tolerance, shipped plans
+
+--randn: BASELINE.json's floating-point bar ("every shape must match torch.matmul within 1e-2 rel (fp16 acc) / 1e-3 rel
+(fp32 acc)"; the reference itself has no such test, zero_one_correctness_check.py:65-92 is 0/1 only): per shape N(0,1)
+operands (the top-left sub-problem of one 16384^3 pair), both entry points, relative error max|C - ref| / max|ref| <= 1e-3
+over >= 128 sampled rows of C (all of them when M <= 128; the first and last row, the rows either side of every 64 / 96-row
+tile seam that is sampled, random ones otherwise).  ref = the fp32 product of the sampled rows computed on the CPU
+(torch fp32, the oracle expression's arithmetic) when it is cheap (N * K <= 2^24) and in fp64 on the GPU otherwise -- neither
+involves the library under test.  What 0/1 inputs cannot see is seen here: the fp32 -> fp16 rounding of the epilogue,
+fractional partial sums through the split-K / stream-K slabs, denormal products.
 """
 from __future__ import annotations
 
@@ -73,6 +84,68 @@ def check_output(c: Guarded, truth: torch.Tensor) -> tuple[float, bool]:
     return float(diff.max().item()), bool(torch.equal(out.view(torch.int16), truth.view(torch.int16)))
 
 
+def sample_rows(m: int, rng: np.random.Generator, want: int = 128) -> np.ndarray:
+    """Rows of C the N(0,1) check looks at: all of them up to `want`, else the edges, tile seams and random rows."""
+    if m <= want:
+        return np.arange(m)
+    rows = {0, m - 1}
+    for seam in rng.choice(np.arange(1, m // 32), size=min(16, m // 32 - 1), replace=False) * 32:   # (64 / 96 / 128 / 192 / 256-row tile seams)
+        rows.update((int(seam) - 1, int(seam)))
+    while len(rows) < want:
+        rows.add(int(rng.integers(0, m)))
+    return np.array(sorted(rows))
+
+
+def randn_pass(a, L, stream, shapes) -> int:
+    torch.manual_seed(a.seed)
+    rng = np.random.default_rng(a.seed)
+    dm, dn, dk = (max(s[i] for s in shapes) for i in range(3))
+    a_full = torch.randn((dm, dk), dtype=torch.half, device="cuda")
+    b_full = torch.randn((dk, dn), dtype=torch.half, device="cuda")
+    out_f = open(a.out, "w")
+    t_start = time.time()
+    n_checks = n_fail = 0
+    worst = 0.0
+    for (m, n, k) in shapes:
+        av = a_full[:m, :k].contiguous()
+        bv = b_full[:k, :n].contiguous()
+        btv = bv.t().contiguous()                                   # as_col_major storage (tools/utils.py:110-115)
+        rows = sample_rows(m, rng)
+        ridx = torch.from_numpy(rows).cuda()
+        where = "cpu fp32" if n * k <= (1 << 24) else "gpu fp64"
+        if where == "cpu fp32":
+            ref = (av[ridx].cpu().float() @ bv.cpu().float()).double().cuda()
+        else:
+            ref = av[ridx].double() @ bv.double()
+        scale = float(ref.abs().max().item())
+        cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.hgemm_mi355x_plan(m, n, k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
+        name = L.hgemm_mi355x_config_name(cfg.value)
+        c = torch.empty((m, n), dtype=torch.half, device="cuda")
+        for entry in ("fp32", "fp16"):
+            c.fill_(float("nan"))
+            status = getattr(L, f"hgemm_mi355x_{entry}")(av.data_ptr(), bv.data_ptr(), btv.data_ptr(), c.data_ptr(), m, n, k, stream)
+            torch.cuda.synchronize()
+            got = c[ridx].double()
+            finite = bool(torch.isfinite(c).all().item())          # (whole tile: an unwritten NaN anywhere is a failure)
+            rel = float(((got - ref).abs().max() / max(scale, 1e-30)).item()) if finite else float("inf")
+            ok = status == 0 and finite and rel <= a.rel_tol
+            rec = {"mnk": f"{m}_{n}_{k}", "run": entry, "status": status, "pass": ok, "relative_error": rel, "tolerance": a.rel_tol,
+                   "rows_checked": int(len(rows)), "reference": where, "inputs": "N(0,1)",
+                   "plan": {"config": name.decode() if name else ("ragged" if cfg.value == -2 else "generic"), "splits": sp.value & 0xFFFF,
+                            "fused": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000), "streamk": bool(sp.value & 0x40000),
+                            "group_m": gm.value}}
+            out_f.write(json.dumps(rec) + "\n")
+            n_checks += 1
+            n_fail += 0 if ok else 1
+            worst = max(worst, rel)
+            if not ok:
+                print("FAIL", json.dumps(rec), flush=True)
+    out_f.close()
+    print(json.dumps({"checks": n_checks, "failures": n_fail, "worst_relative_error": worst, "seconds": round(time.time() - t_start, 1), "out": a.out}))
+    return 1 if n_fail else 0
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--shape-file", default=str(REPO / "cuda-l2_amd" / "tools" / "grid_shapes.txt"))
@@ -82,6 +155,8 @@ def main(argv=None) -> int:
     ap.add_argument("--out", required=True)
     ap.add_argument("--repeats", type=int, default=2, help="runs per plan (split-K counters must return to zero)")
     ap.add_argument("--seed", type=int, default=20260925)
+    ap.add_argument("--randn", action="store_true", help="N(0,1) operands, relative tolerance on sampled rows (see the module text)")
+    ap.add_argument("--rel-tol", type=float, default=1e-3)
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("verify_plans needs an MI355X")
@@ -101,6 +176,8 @@ def main(argv=None) -> int:
         shapes = [s for s in shapes if s in cand]
 
     L.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    if a.randn:
+        return randn_pass(a, L, stream, shapes)
     rng = np.random.default_rng(a.seed)
     out_f = open(a.out, "w")
     t_start = time.time()
@@ -158,7 +235,7 @@ def main(argv=None) -> int:
                     if c is None:
                         rec["plan"] = {"config": name.decode() if name else ("ragged" if cfg.value == -2 else "generic"),
                                        "splits": sp.value & 0xFFFF, "fused": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000),
-                                       "group_m": gm.value}
+                                       "streamk": bool(sp.value & 0x40000), "group_m": gm.value}
                     else:
                         rec["plan"] = {"config": c["config"], "splits": c["splits"], "group_m": c["group_m"]}
                     out_f.write(json.dumps(rec) + "\n")
