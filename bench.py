@@ -458,7 +458,7 @@ def main(argv=None):
             # strongest hipBLASLt variant (autotune or heuristic, tn or nn) on the workload shape, same run, back-to-back launches
             w = result["shapes"].get(prob.mnk, {})
             if "speedup_vs_hipblaslt_auto_max" in w:
-                lt_us = w["ours_us"] / w["speedup_vs_hipblaslt_auto_max"]
+                lt_us = w["ours_us"] * w["speedup_vs_hipblaslt_auto_max"]     # speedup = hipBLASLt time / our time
                 result["vs_hipblaslt_autotune_max"] = {"ratio": round(w["speedup_vs_hipblaslt_auto_max"], 4), "ours_tflops": round(w["ours_tflops"], 1),
                                                        "hipblaslt_tflops": round(prob.flops / lt_us * 1e-6, 1), "clock": "HIP events, back-to-back launches, same run"}
         if world == 1 and not args.no_cpu_baseline:

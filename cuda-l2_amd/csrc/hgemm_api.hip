@@ -328,6 +328,17 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     if (!k_ok(e, K)) continue;
     if ((e.bm > M * 2 && e.bm > 32) || (e.bn > N * 2 && e.bn > 32)) continue;   // mostly padding
     const int ksteps = std::max(1, K / e.kgran);
+    // a stream-K corner plan keeps its form (the low bits are its workgroup count, not a split count) and is priced as such
+    if ((p->splits & HGEMM_PLAN_STREAMK) && e.sk_wgs_per_cu > 0) {
+      const double t = model_us_streamk(e, M, N, K, streamk_grid(e, p->splits & HGEMM_SPLITK_MASK));
+      if (t < best) {
+        best = t; found = true;
+        *cfg = p->cfg;
+        *splits = HGEMM_PLAN_STREAMK | (p->splits & HGEMM_SPLITK_MASK);
+        *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
+      }
+      continue;
+    }
     const int s = std::max(1, std::min(p->splits & HGEMM_SPLITK_MASK, ksteps));
     // the 8-wave mid tiles were tuned (and the model fitted) for at most two workgroups per CU: beyond that the larger tiles of
     // another corner win (1332 x 3108 x 4440: 525 tiles of 64 x 128 measured 101 us against 82 us for the 256 x 256 corner plan)
@@ -338,6 +349,8 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       best = t; found = true;
       *cfg = p->cfg;
       *splits = s > 1 ? (s | (p->splits & HGEMM_SPLITK_FUSED)) : 1;
+      // family r's load flags travel with the corner plan (they belong to the access pattern of the shape class, not to the shape)
+      if (e.name[0] == 'r') *splits |= p->splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS);
       *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
     }
   }
@@ -346,7 +359,7 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   // ranking with the split count of the best corner and unsplit (the model prices the members of family q on one scale:
   // measured / modelled 1.39-1.42 for all of them, tuning/r03_late_tune_mi355x.jsonl).
   if (found && K % 64 == 0) {
-    const int best_s = std::max(1, *splits & HGEMM_SPLITK_MASK), best_fused = *splits & HGEMM_SPLITK_FUSED;
+    const int best_s = (*splits & HGEMM_PLAN_STREAMK) ? 1 : std::max(1, *splits & HGEMM_SPLITK_MASK), best_fused = *splits & HGEMM_SPLITK_FUSED;
     const char* extra[2] = {(M % 192 == 0 && N >= 128) ? "q192x256_w2x2" : nullptr,
                             (N % 192 == 0 && M >= 128) ? "q256x192_w2x2" : nullptr};
     for (const char* name : extra) {
@@ -552,7 +565,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.k_chunk = K; g.splits = 1; g.tiles_m = g.tiles_n = 1; g.group_m = 1; g.items = 1;
   g.tail_first = 0; g.tail_tiles = 0;
-  g.flags = (splits_arg & HGEMM_PLAN_NT_STORE) ? 1 : 0;
+  g.flags = ((splits_arg & HGEMM_PLAN_NT_STORE) ? 1 : 0) | ((splits_arg & HGEMM_PLAN_RS_XCD_STAGGER) ? 2 : 0) | ((splits_arg & HGEMM_PLAN_RS_NT_LOADS) ? 4 : 0);
   g.sk = StreamK{1, 0, 0, 1, FastDiv{0u, 0u, 0u}};
 #ifdef HGEMM_ABLATION
   g.debug = g_debug_flags;

@@ -198,7 +198,8 @@ struct GemmArgs {
   // Single-launch split-K (EPI_FUSED): one arrival counter per output tile (zero before the launch, reset
   // by the last arriver) and compact per-item slabs partial[item][BM*BN] in the kernel's own lane order.
   unsigned* counters;
-  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE)
+  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE); family r: bit 1 K stagger per XCD instead of per tile
+                   // (HGEMM_PLAN_RS_XCD_STAGGER), bit 2 non-temporal loads of the streamed operand (HGEMM_PLAN_RS_NT_LOADS)
 #if HGEMM_FASTDIV
   RasterDiv rd;    // multipliers for the raster map's divisions (set_raster_div on the host, after the fields above are final)
 #endif

@@ -157,9 +157,11 @@ __device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, i
 
   f16x8 ra0[CA], rb0[CB], ra1[CA], rb1[CB];      // two stages in flight
   constexpr int kAuxNt = 2;   // buffer aux operand: bit 1 = nt
-  const bool nt_a = HGEMM_RS_NT == 2 || (HGEMM_RS_NT == 1 && g.M >= g.N);
-  const bool nt_b = HGEMM_RS_NT == 2 || (HGEMM_RS_NT == 1 && g.M < g.N);
-  const unsigned stg_id = HGEMM_RS_STAGGER_MODE == 1 ? (blockIdx.x % NUM_XCD) * (unsigned)max(1, nk / NUM_XCD)
+  // (plan flags, GemmArgs::flags bits 1 and 2: wave-uniform; the build-time knobs force them for experiment builds)
+  const bool nt_streamed = HGEMM_RS_NT == 1 || (g.flags & 4) != 0;
+  const bool nt_a = HGEMM_RS_NT == 2 || (nt_streamed && g.M >= g.N);
+  const bool nt_b = HGEMM_RS_NT == 2 || (nt_streamed && g.M < g.N);
+  const unsigned stg_id = (HGEMM_RS_STAGGER_MODE == 1 || (g.flags & 2) != 0) ? (blockIdx.x % NUM_XCD) * (unsigned)max(1, nk / NUM_XCD)
                         : HGEMM_RS_STAGGER_MODE == 2 ? (tile_id % 8u) * (unsigned)max(1, nk / 8) : tile_id * (unsigned)HGEMM_RS_STAGGER;
   const int stage0 = HGEMM_RS_STAGGER ? (int)(stg_id % (unsigned)nk) : 0;
 #define RS_STAGE(T) ((stage0 + (T)) >= nk ? (stage0 + (T)) - nk : (stage0 + (T)))

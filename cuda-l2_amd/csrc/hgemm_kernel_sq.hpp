@@ -43,14 +43,11 @@
 #ifndef HGEMM_SQ_RS64
 #define HGEMM_SQ_RS64 2       // leading reads every N slots when an interval has >= 64 slots
 #endif
-#ifndef HGEMM_SQ_XSTAGGER
-#define HGEMM_SQ_XSTAGGER 0   // 1: the workgroups of XCD x start every K walk at stage x * nk / 8 (and wrap around): the
-                              // XCDs stop reading the same K offsets at the same time, each XCD's workgroups stay in
-                              // lock-step (their L2 sharing of the A / B panels is untouched).
-                              // BROKEN for the non-square members (round 3, `hgemm_tune check --plan-flags`: 256x128, 128x256,
-                              // 192x256, 256x192 compute wrong results with it, the square members are exact;
-                              // profiles/r03_check_q_xstagger_variant_FAILS.log): timing experiments on square tiles only
-#endif
+// (Round 3 had an experiment knob here, HGEMM_SQ_XSTAGGER: a per-XCD K stagger of every work item's K walk.  It computed wrong
+// results for every non-square member -- profiles/withdrawn/r03_check_q_xstagger_variant_FAILS.log -- and was removed from the
+// source in round 4: no switch of this header selects a kernel that has not passed `hgemm_tune check`.  The stagger that the
+// lock-step one-tile-per-CU plans lack comes from the plans themselves now: split-K / stream-K parts of a tile start their K
+// walks at different offsets.)
 #ifndef HGEMM_SQ_QORDER
 #define HGEMM_SQ_QORDER 0     // behind Q: 0 = B-fragment reads lead the A pieces, 1 = the pieces lead
 #endif
@@ -389,21 +386,15 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
     const unsigned range_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(rem_ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)rem_)); \
     if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
     else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
-    {                                                                                                          \
-      const int s0_ = (HGEMM_SQ_XSTAGGER && nxt_nk >= 8) ? (int)(blockIdx.x % NUM_XCD) * (nxt_nk / NUM_XCD) : 0; \
-      cur[OP].kbyte = (uint32_t)nxt_kb + (uint32_t)s0_ * (CFG::KT * ROW_BYTES);                                \
-      cur[OP].wrap_kt = nxt_nk - s0_;   /* the walk wraps to the item's first stage when kt reaches this */   \
-    }                                                                                                          \
+    cur[OP].kbyte = (uint32_t)nxt_kb;                                                                          \
     cur[OP].item = (ITEM); cur[OP].kt = 0; cur[OP].nk = nxt_nk;                                                \
   } while (0)
 
-// one stage on inside the current item (with the wrap of a staggered walk)
+// one stage on inside the current item
 #define SQ_STEP_CURSOR(OP)                                                                   \
   do {                                                                                       \
     ++cur[OP].kt;                                                                            \
     cur[OP].kbyte += CFG::KT * ROW_BYTES;                                                    \
-    if (HGEMM_SQ_XSTAGGER && cur[OP].kt == cur[OP].wrap_kt)                                  \
-      cur[OP].kbyte -= (uint32_t)cur[OP].nk * (CFG::KT * ROW_BYTES);                         \
   } while (0)
 
 // Move a stream one K-step on; past the last step of the last item it stays put (the branch-free DMA then
@@ -497,7 +488,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   for (int q = 0; q < CFG::PA; ++q) voffA[q] = ((uint32_t)((wave + q * CFG::NW) * 8 + (lane >> 3)) * (uint32_t)g.lda + chunk0 * 8u) * 2u;
 #pragma unroll
   for (int q = 0; q < CFG::PB; ++q) voffB[q] = ((uint32_t)((wave + q * CFG::NW) * 8 + (lane >> 3)) * (uint32_t)g.ldb + chunk0 * 8u) * 2u;
-  struct Cursor { uint32_t kbyte; int item, kt, nk, wrap_kt; } cur[2];
+  struct Cursor { uint32_t kbyte; int item, kt, nk; } cur[2];
   int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
   SQ_LOAD_ITEM(0, 0);
   SQ_LOAD_ITEM(1, 0);

@@ -81,6 +81,8 @@ static std::vector<Shape> read_shape_file(const char* path) {
   return out;
 }
 
+static size_t g_pad_alloc_mib = 0;  // --pad-alloc N: a dummy N-MiB allocation in front of the operand sets (moves their physical placement:
+                                    // lock-step K walks over 32-KiB-strided rows are sensitive to which HBM channels the rows land on)
 static int g_ld_override = -1;     // --ld N: pass lda = ldb = N (0 = every tile row aliases row 0: cache-hit ablation)
 static bool g_zero_fill = false;  // --fill zero: DVFS experiment only (never for quoted numbers)
 
@@ -322,7 +324,11 @@ static int cmd_check(const std::vector<Shape>& shapes) {
       // stream-K forms (geometries that have the kernel): one resident wave of workgroups, and small odd grids that cut tiles
       // at odd stages and give every workgroup several segments
       for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED, HGEMM_PLAN_STREAMK, 5 | HGEMM_PLAN_STREAMK,
-                         37 | HGEMM_PLAN_STREAMK, 300 | HGEMM_PLAN_STREAMK}) {
+                         37 | HGEMM_PLAN_STREAMK, 300 | HGEMM_PLAN_STREAMK,
+                         // family r's plan flags (K stagger per XCD, non-temporal loads of the streamed operand), alone and combined
+                         1 | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS, 2 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_RS_XCD_STAGGER,
+                         3 | HGEMM_PLAN_RS_NT_LOADS, 37 | HGEMM_PLAN_STREAMK | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS}) {
+        if ((splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS)) && (c < 0 || hgemm_mi355x_config_name(c)[0] != 'r')) continue;
         const bool sk = (splits & HGEMM_PLAN_STREAMK) != 0;
         const int sp = sk ? 2 : (splits & HGEMM_SPLITK_MASK);   // (sp > 1: run twice, one raster group)
         if (sk && (c < 0 || hgemm_mi355x_config_streamk(c) <= 0)) continue;
@@ -361,6 +367,15 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     printf("checked %d_%d_%d\n", sh.M, sh.N, sh.K);
     fflush(stdout);
   }
+  // what this log covers, machine-readable (tests/test_evidence_consistency.py: a tuner result is only committed beside a
+  // check log that names every geometry it times)
+  printf("check-configs:");
+  for (int c = HGEMM_CONFIG_RAGGED; c < nc; ++c) {
+    const char* cname = c >= 0 ? hgemm_mi355x_config_name(c) : (c == HGEMM_CONFIG_GENERIC ? "generic" : "ragged");
+    if (g_config_filter.empty() || std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) != g_config_filter.end())
+      printf(" %s", cname);
+  }
+  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, raster groups 1 4\n");
   printf("check: %d runs, %d failures (bit-exact against the exact integer result of 0/1 inputs)\n", runs, failures);
   return failures ? 1 : 0;
 }
@@ -843,6 +858,7 @@ int main(int argc, char** argv) {
     else if (a == "--seconds") g_seconds = atof(next());
     else if (a == "--baseline") { g_baseline = next(); g_power = true; }
     else if (a == "--ld") g_ld_override = atoi(next());
+    else if (a == "--pad-alloc") g_pad_alloc_mib = (size_t)atol(next());
     else if (a == "--debug") {
       if (!hgemm_mi355x_set_debug) { fprintf(stderr, "--debug needs the ablation build of the library (lib_ablation/)\n"); return 2; }
       hgemm_mi355x_set_debug(atoi(next()));
@@ -854,6 +870,11 @@ int main(int argc, char** argv) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     fprintf(stderr, "hgemm_tune: no HIP device visible\n");
     return 3;
+  }
+  if (g_pad_alloc_mib) {
+    void* pad = nullptr;
+    HIP_OK(hipMalloc(&pad, g_pad_alloc_mib << 20));   // (kept until exit)
+    HIP_OK(hipMemset(pad, 1, g_pad_alloc_mib << 20));
   }
   if (mode == "check") {
     if (shapes.empty())

@@ -1,6 +1,6 @@
 // M=16384 N=64 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry r128x64_k128, split-K 2 (single launch), raster group 16  [tuned on MI355X: 99.3 us, 346 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r128x64_k128_d, split-K 2 (single launch), raster group 4  [tuned on MI355X (round 4): 97.9 us, 351.0 TFLOP/s fused split-K (back to back 96.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 64, 16384, "r128x64_k128", 65538, 16)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 64, 16384, "r128x64_k128_d", 1114114, 4)

@@ -1,6 +1,6 @@
 // M=128 N=256 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t32x64_w1x2_m16_s4, split-K 16, raster group 8  [tuned on MI355X: 9.9 us, 27 TFLOP/s, verified against the CPU oracle]
+// plan: geometry w16x16_k4, split-K 2 (single launch), raster group 4  [tuned on MI355X (round 4): 10.5 us, 25.5 TFLOP/s fused split-K (back to back 8.1 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 256, 4096, "t32x64_w1x2_m16_s4", 16, 8)
+HGEMM_MI355X_SHAPE_ENTRY(128, 256, 4096, "w16x16_k4", 65538, 4)

@@ -1,6 +1,6 @@
 // M=64 N=16384 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry r64x64_k256, split-K 2 (single launch), raster group 32  [tuned on MI355X: 95.2 us, 361 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r64x128_k128_d, split-K 2 (single launch), raster group 4  [tuned on MI355X (round 4): 90.2 us, 381.1 TFLOP/s fused split-K (back to back 86.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 16384, 16384, "r64x64_k256", 65538, 32)
+HGEMM_MI355X_SHAPE_ENTRY(64, 16384, 16384, "r64x128_k128_d", 1114114, 4)

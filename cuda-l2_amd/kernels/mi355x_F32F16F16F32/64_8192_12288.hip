@@ -1,6 +1,6 @@
 // M=64 N=8192 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 2 (single launch), raster group 4  [tuned on MI355X: 54.1 us, 238 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r64x128_k128, split-K 4 (single launch), raster group 1  [tuned on MI355X (round 4): 42.2 us, 305.2 TFLOP/s fused split-K (back to back 39.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 12288, "t64x64_w2x2_m16_s4", 65538, 4)
+HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 12288, "r64x128_k128", 1638404, 1)

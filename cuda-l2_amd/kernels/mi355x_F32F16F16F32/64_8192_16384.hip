@@ -1,6 +1,6 @@
 // M=64 N=8192 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry r64x128_k128, split-K 4 (single launch), raster group 1  [tuned on MI355X: 47.8 us, 360 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r64x128_k128_d, split-K 4 (single launch), raster group 1  [tuned on MI355X (round 4): 50.1 us, 343.0 TFLOP/s fused split-K (back to back 48.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 16384, "r64x128_k128", 65540, 1)
+HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 16384, "r64x128_k128_d", 1114116, 1)

@@ -1,6 +1,6 @@
 // M=8192 N=64 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry r128x64_k128, split-K 4 (single launch), raster group 4  [tuned on MI355X: 55.2 us, 311 TFLOP/s, verified against the CPU oracle]
+// plan: geometry r128x64_k128, split-K 8 (single launch), raster group 2  [tuned on MI355X (round 4): 57.0 us, 301.3 TFLOP/s fused split-K (back to back 54.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 64, 16384, "r128x64_k128", 65540, 4)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 64, 16384, "r128x64_k128", 1114120, 2)

@@ -63,7 +63,7 @@ def write_shape_file(mnk: str, acc: str, device_type: str = "mi355x", plan=None,
     entry = "hgemm_mi355x_fp32" if acc == "fp32" else "hgemm_mi355x_fp16"
     text = (
         f"// M={m} N={n} K={k}  {ACC_TEXT[acc]}  MI355X / gfx950\n"
-        f"// plan: geometry {cfg}, split-K {splits & 0xFFFF}{' (single launch)' if splits & 0x10000 else ''}"
+        f"// plan: geometry {cfg}, " + (f"stream-K on {splits & 0xFFFF} workgroups" if splits & 0x40000 else f"split-K {splits & 0xFFFF}{' (single launch)' if splits & 0x10000 else ''}") +
         f"{', non-temporal C stores' if splits & 0x20000 else ''}, raster group {group}  [{source}]\n"
         f"// kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def\n"
         f"#define HGEMM_SHAPE_FALLBACK {entry}\n"

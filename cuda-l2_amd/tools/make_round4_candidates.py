@@ -31,6 +31,8 @@ def main(argv=None) -> int:
     ap.add_argument("--below", type=float, default=1.08)
     ap.add_argument("--top-sk", type=int, default=6)
     ap.add_argument("--shapes-out", default="", help="also write the selected shapes, one per line")
+    ap.add_argument("--pass2", action="store_true", help="second pass: family w beyond the first pass's domain (K <= 512 on outputs up to 2048^2 for "
+                    "the one-wave-per-tile members, K >= 256 on outputs up to 1024^2 for the _k4 members), against the table as it stands")
     a = ap.parse_args(argv)
     import build
 
@@ -59,6 +61,29 @@ def main(argv=None) -> int:
         flops = 2.0 * m * n * k
         lt = min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"])
         toks = []
+        if a.pass2:
+            first = (k <= 128) or (m * n <= 256 * 256 and k >= 512)          # the first pass's family-w domain
+            for cf in cfgs:
+                if cf["name"][0] != "w" or not fits(cf, m, n, k) or first:
+                    continue
+                k4 = cf["name"].endswith("_k4")
+                tiles = -(-m // cf["bm"]) * -(-n // cf["bn"])
+                if not k4 and k <= 512 and m * n <= 2048 * 2048 and tiles <= 4096:
+                    toks.append(f"{cf['name']}:1:{grp(cf, m, n)}")
+                if k4 and k >= 256 and m * n <= 1024 * 1024:
+                    for s in (1, 2, 4, 8, 16):
+                        per = k // s
+                        if per < 256 or per % 64 or tiles * s > 2048 or (tiles * s < 64 and s < 16):
+                            continue
+                        toks.append(f"{cf['name']}:{s | (FUSED if s > 1 else 0)}:{grp(cf, m, n)}")
+            if toks:
+                cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                L.hgemm_mi355x_plan(m, n, k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
+                if cfg.value >= 0:
+                    toks.insert(0, f"{L.hgemm_mi355x_config_name(cfg.value).decode()}:{sp.value}:{gm.value}")
+                print(r["mnk"], *dict.fromkeys(toks))
+                selected.append(r["mnk"])
+            continue
         want_sk = flops >= 1e9 and ((r["best"]["splits"] & 0xFFFF) > 1 or lt / r["best"]["us"] < a.below)
         skinny = min(m, n) <= 256 and k >= 2048 and max(m, n) >= 2048
         tiny_k = k <= 128

@@ -40,6 +40,10 @@ CSV_COLUMNS = ["torch.matmul", "rocBLAS-tn", "rocBLAS-nn", "rocBLAS-max", "hipBL
                "hipBLASLt-auto-tuning-nn", "hipBLASLt-auto-tuning-max"]
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_TBPS = 8.0             # HBM3E spec
+
+
 def shard(shapes: list[str], rank: int, world: int) -> list[str]:
     """Round-robin partition: every shape costs ~the same wall time (fixed warm-up + benchmark seconds),
     so shapes[rank::world] balances the ranks; the union over ranks is exactly `shapes`."""
@@ -180,9 +184,16 @@ def merge(out: Path, acc: str, mode: str, shapes: list[str]) -> dict:
         for r in rows:
             f.write(r[0] + "," + ",".join(f"{v:.3f}" for v in r[1:]) + "\n")
     with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_tflops_{mode}.csv", "w") as f:
-        f.write("mnk,cuda_l2_tflops,hipblaslt_autotune_max_tflops,torch_matmul_tflops,cpu_torch_matmul_tflops\n")
+        # north_star: "report per-shape TFLOP/s ... with achieved %-of-fp16-MFMA-peak".  Two percentages of OUR figure (the
+        # reference's host wall-clock TFLOPS, so launch-bound shapes read low by construction): of the dense fp16 MFMA peak
+        # (2.5 PFLOP/s), and of the shape's own roofline min(peak, arithmetic intensity x 8 TB/s) with the algorithmic bytes
+        # 2 (MK + KN + MN)
+        f.write("mnk,cuda_l2_tflops,hipblaslt_autotune_max_tflops,torch_matmul_tflops,cpu_torch_matmul_tflops,cuda_l2_pct_of_fp16_mfma_peak,cuda_l2_pct_of_roofline\n")
         for r in tf_rows:
-            f.write(r[0] + "," + ",".join("" if v is None else format(v, ".4f" if i == 3 else ".3f") for i, v in enumerate(r[1:])) + "\n")
+            m_, n_, k_ = (int(x) for x in r[0].split("_"))
+            roof = min(MFMA_F16_PEAK_TFLOPS, flops(r[0]) / (2.0 * (m_ * k_ + k_ * n_ + m_ * n_)) * HBM_PEAK_TBPS)
+            pct = ["" if r[1] is None else f"{100.0 * r[1] / MFMA_F16_PEAK_TFLOPS:.3f}", "" if r[1] is None else f"{100.0 * r[1] / roof:.3f}"]
+            f.write(r[0] + "," + ",".join("" if v is None else format(v, ".4f" if i == 3 else ".3f") for i, v in enumerate(r[1:])) + "," + ",".join(pct) + "\n")
     if lat_rows:
         with open(out / f"cuda_l2_mi355x_{ACC_DIRS[acc]}_latency_{mode}.csv", "w") as f:
             f.write("mnk,cuda_l2_p50_ms,cuda_l2_p99_ms,hipblaslt_tn_p50_ms,hipblaslt_tn_p99_ms\n")

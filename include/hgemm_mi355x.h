@@ -67,7 +67,10 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * C is written once and never re-read; streaming stores leave the device during the epilogue instead of sitting dirty in
  * the XCDs' write-back L2s until the end-of-kernel release.  Measured back to back on MI355X (round 3): the gap between
  * two launches shrinks from 3.7 to 2.0 us; 4096^3 -4 %, 8192 x 16384 x 256 -8 %, 16384^2 x 256 +1.5 %: the tuner decides
- * per shape.  Results are bit-identical either way. */
+ * per shape.  Results are bit-identical either way.
+ * Honoured by the direct fp16 epilogues of every family (whole tiles of a stream-K run and the last arriver of a single-launch
+ * split-K included); ignored by the two-pass combine kernel, the hybrid tail's reduce and the any-shape kernels; the off-grid
+ * planner does not propagate it from a corner plan. */
 #define HGEMM_PLAN_NT_STORE 0x20000
 /* Plan flag: STREAM-K (the reference's H100 tree: cutlass::gemm::StreamKScheduler, kernels/h100_F32F16F16F32/
  * 128_4096_16384.cu:79, 16384_512_2048.cu:71-73).  One persistent launch: the tiles x K-stages of the GEMM form one
@@ -77,10 +80,17 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * workgroups per CU).  At most the first and the last segment of a run are partial tiles; they go through compact fp32
  * slabs and per-tile arrival counters, the workgroup that completes a tile adds its parts in K order (deterministic, nobody
  * waits).  Geometries of the classic ("t") and register-staged ("r") families have the kernel
- * (hgemm_mi355x_config_streamk); elsewhere, or without workspace, the plan runs as the geometry's plain launch.
- * HGEMM_PLAN_NT_STORE is honoured by the direct fp16 epilogues (every family, whole tiles of a stream-K run included); the
- * two-pass combine kernel and the any-shape kernels ignore it. */
+ * (hgemm_mi355x_config_streamk); elsewhere, or without workspace, the plan runs as the geometry's plain launch. */
 #define HGEMM_PLAN_STREAMK 0x40000
+/* Plan flags of the register-staged streaming family ("r" geometries; ignored elsewhere).  Results are exact either way (0/1
+ * inputs) / differ only in the summation order of a tile's K walk (N(0,1) inputs), deterministically per plan.
+ * HGEMM_PLAN_RS_XCD_STAGGER: the K stagger of the family (workgroups start their K walk at different stages so that the chip does
+ *   not read one K offset of rows 16-32 KiB apart at the same time) is taken per XCD instead of per tile: the workgroups of an
+ *   XCD walk K in lock-step and share the slices of the small operand in that XCD's L2; the eight XCDs are nk / 8 stages apart.
+ * HGEMM_PLAN_RS_NT_LOADS: the STREAMED operand (the one with more rows, read exactly once) is loaded non-temporally, so it does
+ *   not push the shared operand's slices out of the L2 (what hipBLASLt's kernels do on the skinny shapes: NTA / NTB). */
+#define HGEMM_PLAN_RS_XCD_STAGGER 0x80000
+#define HGEMM_PLAN_RS_NT_LOADS    0x100000
 
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)

@@ -144,6 +144,123 @@ def test_m0_writes_and_lds_dma_loads_alternate_in_the_k_loops(sp_functions):
     assert checked >= 6
 
 
+def m0_provenance_violations(lines):
+    """Whole-function M0 audit: family q writes M0 and issues the LDS-DMA load as two asm statements without telling the
+    compiler (an "m0" clobber makes hipcc pad every pair with an s_nop in the MFMA gaps).  So nothing but the ISA can show that
+    the compiler never slips an M0 write of its own between a pair, on ANY path: every asm-statement `buffer_load ... lds` must
+    be reached only by asm-statement M0 writes -- over the control-flow graph, not just textually.  Returns the offending loads.
+    (Compiler-generated LDS-DMA, the builtin form used outside the K loops, sets M0 itself and is not subject to this.)"""
+    blocks, cur, in_asm = [], {"label": None, "code": []}, False
+    for ln in lines:
+        if "#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if "#ASMEND" in ln:
+            in_asm = False
+            continue
+        code = ln.split(";")[0].strip()
+        if not code or code.startswith("#") or (code.startswith(".") and not code.endswith(":")):
+            continue
+        if code.endswith(":"):
+            if cur["code"] or cur["label"] is not None:
+                blocks.append(cur)
+            cur = {"label": code[:-1], "code": []}
+            continue
+        cur["code"].append((code, in_asm))
+        if re.match(r"s_(branch|cbranch_\w+|endpgm|setpc_b64|trap)\b", code):
+            blocks.append(cur)
+            cur = {"label": None, "code": []}
+    if cur["code"] or cur["label"] is not None:
+        blocks.append(cur)
+    index = {b["label"]: i for i, b in enumerate(blocks) if b["label"] is not None}
+    preds = [set() for _ in blocks]
+    for i, b in enumerate(blocks):
+        last = b["code"][-1][0] if b["code"] else ""
+        m = re.match(r"s_(branch|cbranch_\w+)\s+(\S+)", last)
+        if m and m.group(2) in index:
+            preds[index[m.group(2)]].add(i)
+        if i + 1 < len(blocks) and not re.match(r"s_(branch|endpgm|setpc_b64)\b", last):
+            preds[i + 1].add(i)
+    # per-block summary: the last M0 writer inside the block (None: the entry state passes through) and the asm loads, each with
+    # the writer it sees inside the block (None: it sees the entry state)
+    last_w, loads = [], []
+    for b in blocks:
+        w, ls = None, []
+        for code, in_asm in b["code"]:
+            if re.match(r"s_\w+\s+m0\b", code):
+                w = "asm" if in_asm else "compiler"
+            elif in_asm and code.startswith("buffer_load") and code.endswith(" lds"):
+                ls.append((code, w))
+        last_w.append(w)
+        loads.append(ls)
+    entry = [frozenset() for _ in blocks]          # who wrote M0 last, over all paths: subset of {"asm", "compiler"}
+    for _ in range(len(blocks) + 2):
+        changed = False
+        for i in range(len(blocks)):
+            e = frozenset().union(*[(frozenset({last_w[p]}) if last_w[p] else entry[p]) for p in preds[i]]) if preds[i] else frozenset()
+            if e != entry[i]:
+                entry[i], changed = e, True
+        if not changed:
+            break
+    else:
+        raise AssertionError("M0 audit did not reach a fixpoint")
+    bad = []
+    for i, ls in enumerate(loads):
+        for code, w in ls:
+            st = frozenset({w}) if w else entry[i]
+            if st != frozenset({"asm"}):
+                bad.append((code, sorted(st)))
+    return bad
+
+
+def test_every_asm_lds_dma_is_fed_by_an_asm_m0_write_on_every_path(sp_functions):
+    funcs, _ = sp_functions
+    pairs = 0
+    for name, lines in funcs.items():
+        if "sq_kernel" not in name:
+            continue
+        bad = m0_provenance_violations(lines)
+        assert not bad, f"{name}: {len(bad)} LDS-DMA loads can see a compiler-written M0, first: {bad[0]}"
+        pairs += sum(1 for ln in lines if ln.split(";")[0].strip().startswith("buffer_load") and ln.split(";")[0].strip().endswith(" lds"))
+    assert pairs > 500
+    # the audit catches a compiler M0 write between a pair, directly and through a side entry
+    a_m0, a_ld = ["#ASMSTART", "s_mov_b32 m0, s5", "#ASMEND"], ["#ASMSTART", "buffer_load_dwordx4 v1, s[0:3], s9 offen lds", "#ASMEND"]
+    assert not m0_provenance_violations(a_m0 + ["v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]"] + a_ld)
+    assert m0_provenance_violations(a_m0 + ["s_mov_b32 m0, -1"] + a_ld)
+    assert m0_provenance_violations(["s_cbranch_scc1 .LBB0_2"] + a_m0 + ["s_branch .LBB0_3", ".LBB0_2:", "s_mov_b32 m0, s7", ".LBB0_3:"] + a_ld)
+    assert m0_provenance_violations(a_ld)          # no M0 write at all in front of the load
+
+
+def test_staged_epilogue_has_no_scalar_load_inside_its_counted_lds_window(sp_functions):
+    """sp_epilogue_staged waits with `s_waitcnt lgkmcnt(4)` for its two ds_read_b128 while the next group's four
+    ds_write_b64 are already queued -- sound only while nothing else counts on lgkmcnt there: SMEM loads share the counter and
+    return out of order.  On the ISA: between the first ds_write_b64 of a staged epilogue and its last buffer_store there is no
+    s_load / s_buffer_load."""
+    funcs, _ = sp_functions
+    seen = 0
+    for name, lines in funcs.items():
+        codes = [ln.split(";")[0].strip() for ln in lines]
+        idx_w = [i for i, c in enumerate(codes) if c.startswith("ds_write_b64")]
+        if not idx_w:
+            continue
+        # runs of the staged epilogue: from a ds_write_b64 to the last buffer_store_dwordx4 before the next K-loop MFMA
+        i = 0
+        while i < len(idx_w):
+            start = idx_w[i]
+            end = start
+            j = start
+            while j < len(codes) and not codes[j].startswith("v_mfma"):
+                if codes[j].startswith("buffer_store_dwordx4"):
+                    end = j
+                j += 1
+            window = codes[start:end + 1]
+            assert not [c for c in window if c.startswith(("s_load", "s_buffer_load"))], f"{name}: scalar load inside the staged epilogue's LDS window"
+            seen += 1
+            while i < len(idx_w) and idx_w[i] <= max(end, start):
+                i += 1
+    assert seen >= 4
+
+
 def _vgprs(tok: str, bank: str = "v") -> set:
     """register numbers of a v / a operand (`a` registers are offset by 1000 so both banks share one set)"""
     base = 0 if bank == "v" else 1000

@@ -28,73 +28,116 @@ def _design():
     return (REPO / "DESIGN.md").read_text()
 
 
+def _shipped():
+    out = {}
+    for ln in (PKG / "csrc" / "hgemm_tuned_table.inc").read_text().splitlines():
+        m = re.match(r'\s*\{(\d+), (\d+), (\d+), "(\w+)", (\d+), (\d+)\}', ln)
+        if m:
+            out[f"{m[1]}_{m[2]}_{m[3]}"] = (m[4], int(m[5]), int(m[6]))
+    return out
+
+
 def test_bench_record_and_its_rocprof_stats_match_the_design_text():
-    b = json.loads((REPO / "profiles" / "r03_bench.json").read_text())
+    b = json.loads((REPO / "profiles" / "r04_bench.json").read_text())
     assert b["metric"] == "HGEMM TFLOP/s" and b["n_gpus"] == 1 and b["dtype"] == "f16" and b["vs_baseline"] is None
-    assert f"{b['value']:.1f}" in _design()                                   # 1443.8
-    assert b["roofline"]["traffic_source"] == "profiles/r03_pmc_4096_4096_4096.json" or b["roofline"]["traffic_source"].startswith("profiles/")
-    rows = list(csv.DictReader(io.StringIO((REPO / "profiles" / "r03_bench_py_kernel_stats.csv").read_text())))
+    assert f"{b['value']:.1f}" in _design()
+    roof = b["roofline"]
+    assert roof["traffic_source"].startswith("profiles/r04_pmc_") and roof["launch_us"] == min(roof["avg_launch_us"], roof["wall_per_call_us"])
+    assert f"{roof['frac']:.3f}" in _design()
+    # the headline's own denominator is consistent with the per-shape report it comes from
+    v = b["vs_hipblaslt_autotune_max"]
+    w = b["shapes"]["4096_4096_4096"]
+    assert abs(v["ratio"] - w["speedup_vs_hipblaslt_auto_max"]) < 1e-3 and abs(v["ours_tflops"] / v["hipblaslt_tflops"] - v["ratio"]) < 2e-3
+    assert f"{v['ratio']:.3f}" in _design()
+    # the profiled run of the same command: its own bench line and its kernel stats are committed together
+    prof = json.loads((REPO / "profiles" / "r04_bench_py_profiled_run.json").read_text())
+    assert prof["config"]["plan"] == b["config"]["plan"] and prof["steps"] == b["steps"] and prof["config"]["batch"] == b["config"]["batch"]
+    rows = list(csv.DictReader(io.StringIO((REPO / "profiles" / "r04_bench_py_kernel_stats.csv").read_text())))
     top = max(rows, key=lambda r: float(r["Percentage"]))
     assert "hgemm_tn_sq_kernel" in top["Name"] and "CfgSQ<256, 256" in top["Name"] and float(top["Percentage"]) > 99.9
+    assert int(top["Calls"]) == (prof["steps"] + prof["warmup"]) * prof["config"]["batch"]
     avg_us = float(top["AverageNs"]) * 1e-3
-    assert f"{avg_us:.2f}" in _design()                                       # 94.84
-    # rocprofv3's average and bench.py's own dispatch-attached events agree (the events include the predecessor's drain)
-    assert 0.97 < avg_us / b["roofline"]["avg_launch_us"] <= 1.0
+    assert f"{avg_us:.2f}" in _design()
+    # the three clocks agree: rocprofv3's kernel average is not above either live clock of the profiled run by more than 1 %
+    assert 0.97 < avg_us / prof["roofline"]["launch_us"] < 1.01
     frac = 2.0 * 4096 ** 3 / avg_us * 1e-6 / 2500.0
-    assert f"{frac:.3f}" in _design()                                         # 0.580
+    assert f"{frac:.3f}" in _design()
 
 
 def test_grid_plan_reports_match_the_design_text():
     import tune_report
 
-    iso = _recs(PKG / "tuning" / "r03_grid_plan_report_mi355x.jsonl")
-    assert len(iso) == 1000
-    g = _gm(min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"] for r in iso)
-    assert f"{g:.3f}" in _design()                                            # 1.089
-    st = _recs(PKG / "tuning" / "r03_grid_plan_report_stream_mi355x.jsonl")
-    assert len(st) == 1000 and all(r["stream_us"] > 0 for r in st)
-    gs = _gm(min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) / r["stream_us"] for r in st)
-    assert f"{gs:.3f}" in _design() and f"{gs:.3f}" in (REPO / "README.md").read_text()   # 1.145
-    out = tune_report.main(str(PKG / "tuning" / "r03_grid_plan_report_stream_mi355x.jsonl"), 0)
-    b2b = out["back_to_back"]
-    assert abs(b2b["geomean_speedup_vs_hipblaslt_heuristic_max"] - gs) < 1e-9
-    assert f"{b2b['by_log10_flops'][11]['geomean']:.3f}" in _design() and f"{b2b['by_log10_flops'][12]['geomean']:.3f}" in _design()
+    rep = _recs(PKG / "tuning" / "r04_grid_plan_report_mi355x.jsonl")
+    assert len(rep) == 1000 and all(r["stream_us"] > 0 for r in rep)
+    g = _gm(min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"] for r in rep)
+    gs = _gm(min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) / r["stream_us"] for r in rep)
+    assert f"{g:.3f}" in _design() and f"{gs:.3f}" in _design() and f"{gs:.3f}" in (REPO / "README.md").read_text()
+    out = tune_report.main(str(PKG / "tuning" / "r04_grid_plan_report_mi355x.jsonl"), 0)
+    assert abs(out["back_to_back"]["geomean_speedup_vs_hipblaslt_heuristic_max"] - gs) < 1e-9
+    for d in (10, 11, 12):
+        assert f"{out['by_log10_flops'][d]['geomean']:.3f}" in _design(), d
     # every reported plan is the shipped plan of that shape
-    shipped = {}
-    for ln in (PKG / "csrc" / "hgemm_tuned_table.inc").read_text().splitlines():
-        m = re.match(r'\s*\{(\d+), (\d+), (\d+), "(\w+)", (\d+), (\d+)\}', ln)
-        if m:
-            shipped[f"{m[1]}_{m[2]}_{m[3]}"] = (m[4], int(m[5]), int(m[6]))
-    for r in iso + st:
+    shipped = _shipped()
+    for r in rep:
         assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]
+    # hipBLASLt-autotune with a real budget on the quarter grid (rows whose plan changed afterwards are not counted)
+    auto = [r for r in _recs(PKG / "tuning" / "r04_quarter_grid_plan_report_autotune_mi355x.jsonl")
+            if (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]]]
+    assert len(auto) >= 230
+    ga = _gm(min(v for v in (r["hipblaslt_auto_tn_us"], r["hipblaslt_auto_nn_us"], r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) if v > 0) / r["best"]["us"] for r in auto)
+    assert f"{ga:.3f}" in _design()
 
 
 def test_off_grid_report_and_parity_records():
-    off = _recs(PKG / "tuning" / "r03_offgrid_plan_report_mi355x.jsonl")
+    off = _recs(PKG / "tuning" / "r04_offgrid_plan_report_mi355x.jsonl")
     assert len(off) == 80
     g = _gm(min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"] for r in off)
-    assert 1.095 < g < 1.105 and "geomean **1.10**" in _design()
-    par = _recs(PKG / "tuning" / "r03_parity_1000.jsonl")
+    assert f"{g:.3f}" in _design()
+    par = _recs(PKG / "tuning" / "r04_parity_1000.jsonl")
     assert len(par) == 2000 and all(r["pass"] for r in par)
-    cand = _recs(PKG / "tuning" / "r03_candidate_parity.jsonl")
-    assert all(r["pass"] for r in cand) and f"{len(cand)} candidate checks" in (REPO / "README.md").read_text()
+    rn = _recs(PKG / "tuning" / "r04_randn_1000.jsonl")
+    assert len(rn) == 2000 and all(r["pass"] for r in rn)
+    assert f"{max(r['relative_error'] for r in rn):.1e}" in _design()
+    for name in ("r04_offgrid_parity.jsonl", "r04_offgrid_randn.jsonl"):
+        recs = _recs(PKG / "tuning" / name)
+        assert len(recs) == 160 and all(r["pass"] for r in recs), name
+    cand = sum(len(_recs(PKG / "tuning" / f)) for f in ("r04_candidate_parity_pass1.jsonl", "r04_candidate_parity_pass2.jsonl",
+                                                         "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl"))
+    assert f"{cand} candidate checks" in (REPO / "README.md").read_text()
+    log = (REPO / "profiles" / "r04_check_final.log").read_text()
+    runs = re.search(r"check: (\d+) runs, 0 failures", log)
+    assert runs and f"{int(runs.group(1))} runs" in _design()
+    named = set(re.search(r"^check-configs:(.*)$", log, re.M).group(1).split())
+    assert {c for c, _, _ in _shipped().values()} <= named               # every shipped geometry is in the closing check
 
 
 def test_pmc_table_feeds_bench_traffic_and_covers_every_geometry_with_five_rows():
     import collections
 
-    tab = json.loads((REPO / "profiles" / "r03_pmc_table.json").read_text())
+    tab = json.loads((REPO / "profiles" / "r04_pmc_table.json").read_text())
     rows = {r["mnk"]: r for r in tab["rows"]}
     for mnk in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
-        d = json.loads((REPO / "profiles" / f"r03_pmc_{mnk}.json").read_text())["dominant_kernel"]
+        d = json.loads((REPO / "profiles" / f"r04_pmc_{mnk}.json").read_text())["dominant_kernel"]
         assert d["mnk"] == mnk and abs(d["hbm_bytes_per_launch"] - rows[mnk]["hbm_bytes_per_launch"]) < 1
-    counts = collections.Counter()
-    for ln in (PKG / "csrc" / "hgemm_tuned_table.inc").read_text().splitlines():
-        m = re.match(r'\s*\{\d+, \d+, \d+, "(\w+)", \d+, \d+\}', ln)
-        if m:
-            counts[m[1]] += 1
+    counts = collections.Counter(c for c, _, _ in _shipped().values())
     covered = {r["plan"]["config"] for r in tab["rows"] if r["plan"]}
     assert {c for c, n in counts.items() if n >= 5} <= covered
+    r = rows["16384_128_16384"]
+    assert f"{r['traffic_ratio']:.2f}" in _design()                      # the row section 6.6 builds its reading on
+
+
+def test_sweep_readme_is_generated_from_the_records():
+    import sweep_readme
+
+    root = PKG / "eval_results" / "r04_sweep"
+    text = sweep_readme.build(root, PKG / "tuning" / "r04_grid_plan_report_mi355x.jsonl", PKG / "tuning" / "r04_quarter_grid_plan_report_autotune_mi355x.jsonl")
+    assert (root / "README.md").read_text() == text
+    for acc, mode in (("fp32", "offline"), ("fp16", "offline"), ("fp32", "server"), ("fp16", "server")):
+        d = json.loads((root / f"merge_{acc}_{mode}.json").read_text())
+        assert d["shapes"] == 1000
+        assert f"{d['geomean_speedup_vs_hipBLASLt-auto-tuning-max']:.3f}" in _design() and f"{d['geomean_speedup_vs_hipBLASLt-auto-tuning-max']:.3f}" in (REPO / "README.md").read_text()
+    hdr = (root / "cuda_l2_mi355x_F32F16F16F32_tflops_offline.csv").read_text().splitlines()[0]
+    assert hdr.endswith("cuda_l2_pct_of_fp16_mfma_peak,cuda_l2_pct_of_roofline")
 
 
 def test_late_candidate_generator_starts_every_line_with_the_shipped_plan(capsys):
@@ -120,3 +163,35 @@ def test_late_candidate_generator_starts_every_line_with_the_shipped_plan(capsys
         for c in cands:
             name, s, g = c.rsplit(":", 2)
             assert L.hgemm_mi355x_config_by_name(name.encode()) >= 0 and int(s) & 0xFFFF >= 1 and int(g) >= 1
+
+
+def test_tuner_results_were_checked_before_they_were_timed():
+    """Process rule of round 4 (tools/lab/README.md; VERDICT r3: a knob had been A/B-timed on 436 plans before it was ever run through
+    `hgemm_tune check`, and computed wrong results): every round-4 tuner result file under cuda-l2_amd/tuning/ is listed in
+    r04_checked_before_timed.json with the committed check logs that covered the geometries it times; the logs report 0 failures; every
+    geometry that appears in the file is named by one of them (by the log's own `check-configs:` line when it has one); and in the lab
+    script of the call the check comes before the tune."""
+    man = json.loads((PKG / "tuning" / "r04_checked_before_timed.json").read_text())
+    tune_files = sorted(p for p in (PKG / "tuning").glob("r04_*_mi355x.jsonl") if "plan_report" not in p.name)
+    assert tune_files
+    for tf in tune_files:
+        key = f"tuning/{tf.name}"
+        assert key in man, f"{key}: no check evidence recorded -- a tuner result is not committed without it"
+        covered = set()
+        for entry in man[key]["logs"]:
+            text = (REPO / entry["log"]).read_text()
+            assert re.search(r"check: \d+ runs, 0 failures", text), entry["log"]
+            own = re.search(r"^check-configs:(.*)$", text, re.M)
+            covered |= set(own.group(1).split()) if own else set(entry["configs"])
+        timed = set()
+        for r in _recs(tf):
+            timed |= {c["config"] for c in r["candidates"]}
+        assert timed <= covered, f"{key}: timed but never checked: {sorted(timed - covered)[:5]}"
+        script = (PKG / man[key].get("checked_in", man[key]["script"])).read_text()
+        # (a script with several experiments names the two lines: the check that wrote the log, the tune that wrote the result)
+        ci = script.index(man[key]["check_marker"]) if "check_marker" in man[key] else script.index(" check")
+        ti = script.index(man[key]["tune_marker"]) if "tune_marker" in man[key] else script.index(" tune ")
+        assert " check" in script and ci < ti, man[key]["script"]
+    # plan-only reports time shipped plans (the table's own parity records cover those): nothing else may be in them
+    for rep in (PKG / "tuning").glob("r04_*plan_report*_mi355x.jsonl"):
+        assert all(len(r["candidates"]) == 1 for r in _recs(rep)), rep.name

@@ -5,6 +5,7 @@ bars either side of every operand, NaN-prefilled C, masked difference exactly 0,
 plan run twice (split-K arrival counters must return to zero).  Two operand seeds for the grid.  (~25 s per grid pass.)
 """
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -21,6 +22,13 @@ def _run(tmp_path, name, extra):
 
     out = tmp_path / f"{name}.jsonl"
     rc = verify_plans.main(["--out", str(out), *extra])
+    # HGEMM_RECORD_DIR: keep the records of this run (the committed cuda-l2_amd/tuning/r04_parity_1000.jsonl and
+    # r04_randn_1000.jsonl are the grid passes of one `-m gpu` run: tools/lab/gpu_round4_d.sh)
+    if os.environ.get("HGEMM_RECORD_DIR"):
+        import shutil
+
+        Path(os.environ["HGEMM_RECORD_DIR"]).mkdir(parents=True, exist_ok=True)
+        shutil.copy(out, Path(os.environ["HGEMM_RECORD_DIR"]) / f"{name}.jsonl")
     recs = [json.loads(ln) for ln in out.read_text().splitlines()]
     bad = [r for r in recs if not r["pass"]]
     assert rc == 0 and not bad, bad[:5]

@@ -78,7 +78,7 @@ def test_planner_returns_a_valid_plan(lib, mnk):
     assert lib.hgemm_mi355x_plan(*mnk, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert 0 <= cfg.value < lib.hgemm_mi355x_num_configs()
     count = splits.value & 0xFFFF          # | 0x10000 = HGEMM_SPLITK_FUSED (single-launch form), | 0x20000 = HGEMM_PLAN_NT_STORE,
-    assert splits.value & ~0x7FFFF == 0    # | 0x40000 = HGEMM_PLAN_STREAMK (the count is then the number of persistent workgroups)
+    assert splits.value & ~0x1FFFFF == 0   # | 0x40000 = HGEMM_PLAN_STREAMK (the count is then the number of persistent workgroups), | 0x80000 / 0x100000: family r
     if splits.value & 0x40000:
         assert lib.hgemm_mi355x_config_streamk(cfg.value) > 0 and count <= 4096 and group.value >= 1
     else:
@@ -273,19 +273,29 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
     adopts plans with a passing record of tests/tools/verify_plans.py (the reference's 0/1 rule, bit-exact against
     the CPU oracle, measured on an MI355X); the records are committed and this test ties the table to them."""
     ok = set()
-    for ln in (PKG / "tuning" / "r03_candidate_parity.jsonl").read_text().splitlines():
-        r = json.loads(ln)
-        if r["pass"] and r["bitwise_equal_unmasked"] and r["guard_bars_intact"] and r["max_diff_masked"] == 0.0:
-            ok.add((r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["group_m"]))
+    # (round 3's table + the two passes of the round-4 re-tune, tools/update_tuned_table.py --verified)
+    for name in ("r03_candidate_parity.jsonl", "r04_candidate_parity_pass1.jsonl", "r04_candidate_parity_pass2.jsonl",
+                 "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl"):
+        for ln in (PKG / "tuning" / name).read_text().splitlines():
+            r = json.loads(ln)
+            if r["pass"] and r["bitwise_equal_unmasked"] and r["guard_bars_intact"] and r["max_diff_masked"] == 0.0:
+                ok.add((r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["group_m"]))
     missing = [(m, n, k, c) for (m, n, k, c, s, g) in _tuned_rows() if (f"{m}_{n}_{k}", c, s, g) not in ok]
     assert not missing, missing[:5]
     # ... and the whole-grid run of the SHIPPED table through both entry points (2 x 1000 records, all exact)
-    recs = [json.loads(ln) for ln in (PKG / "tuning" / "r03_parity_1000.jsonl").read_text().splitlines()]
+    recs = [json.loads(ln) for ln in (PKG / "tuning" / "r04_parity_1000.jsonl").read_text().splitlines()]
     assert len(recs) == 2000 and all(r["pass"] and r["bitwise_equal_unmasked"] for r in recs)
     assert {r["run"] for r in recs} == {"fp32", "fp16"} and len({r["mnk"] for r in recs}) == 1000
-    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), g) for (m, n, k, c, s, g) in _tuned_rows()}
+    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), bool(s & 0x40000), (s >> 19) & 3, g) for (m, n, k, c, s, g) in _tuned_rows()}
     for r in recs:
-        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["group_m"]) in shipped, r["mnk"]
+        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["streamk"],
+                r["plan"].get("rs_flags", 0), r["plan"]["group_m"]) in shipped, r["mnk"]
+    # ... and the N(0,1) tolerance of the same table on the whole grid (BASELINE.json: 1e-3 / 1e-2 relative; 1e-3 for both here)
+    rn = [json.loads(ln) for ln in (PKG / "tuning" / "r04_randn_1000.jsonl").read_text().splitlines()]
+    assert len(rn) == 2000 and all(r["pass"] and r["relative_error"] <= 1e-3 and r["rows_checked"] >= 64 for r in rn)
+    for r in rn:
+        assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["streamk"],
+                r["plan"].get("rs_flags", 0), r["plan"]["group_m"]) in shipped, r["mnk"]
 
 
 def test_analytic_model_picks_near_optimal_plans_on_the_measured_candidates(lib):
@@ -436,8 +446,9 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
             corners.add(lib.hgemm_mi355x_config_by_name(b"q256x192_w2x2"))
         assert cfg in corners, (m, n, k, lib.hgemm_mi355x_config_name(cfg))
         assert k % lib.hgemm_mi355x_config_k_granularity(cfg) == 0
-        assert 1 <= (splits & 0xFFFF) <= max(1, k // 64) and group >= 1
-        assert plan(m, n, k) == (cfg, splits, group)
+        # (a stream-K corner plan keeps its form: the low bits are then a workgroup count)
+        assert ((splits & 0x40000) and lib.hgemm_mi355x_config_streamk(cfg) > 0) or 1 <= (splits & 0xFFFF) <= max(1, k // 64)
+        assert group >= 1 and plan(m, n, k) == (cfg, splits, group)
         other = []
         t = threading.Thread(target=lambda: other.append(plan(m, n, k)))
         t.start(); t.join()
@@ -473,7 +484,10 @@ def test_planner_fuzz_every_answer_is_launchable(lib):
         assert 0 <= c.value < n_cfg, (m, n, k, c.value)
         gran = lib.hgemm_mi355x_config_k_granularity(c.value)
         assert k % gran == 0, (m, n, k, lib.hgemm_mi355x_config_name(c.value), gran)
-        assert 1 <= (s.value & 0xFFFF) <= max(1, k // 64) and (s.value & ~0x3FFFF) == 0 and g.value >= 1
+        assert (s.value & ~0x1FFFFF) == 0 and g.value >= 1
+        assert not (s.value & 0x180000) or lib.hgemm_mi355x_config_name(c.value).decode()[0] == "r"   # family r's load flags: r plans only
+        assert ((s.value & 0x40000) and lib.hgemm_mi355x_config_streamk(c.value) > 0 and (s.value & 0xFFFF) <= 4096) or \
+            (not (s.value & 0x40000) and 1 <= (s.value & 0xFFFF) <= max(1, k // 64)), (m, n, k, hex(s.value))
         assert not lib.hgemm_mi355x_config_name(c.value).decode().endswith("_m32") or lib.hgemm_mi355x_config_name(c.value).decode().startswith("t")
 
 
