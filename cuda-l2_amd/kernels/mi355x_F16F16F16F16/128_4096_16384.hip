@@ -1,6 +1,6 @@
 // M=128 N=4096 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry r64x128_k128_d, split-K 4 (single launch), raster group 2  [tuned on MI355X (round 4): 44.7 us, 384.5 TFLOP/s fused split-K (back to back 42.6 us), verified against the CPU oracle]
+// plan: geometry t64x128_w2x2_m16_s4, split-K 4, raster group 2  [tuned on MI355X (round 4): 38.8 us, 443.2 TFLOP/s two-pass split-K (back to back 36.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 4096, 16384, "r64x128_k128_d", 65540, 2)
+HGEMM_MI355X_SHAPE_ENTRY(128, 4096, 16384, "t64x128_w2x2_m16_s4", 4, 2)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-4 call G: closing run on the FINAL tree (family r's plan flags in 34 rows of the table after calls F / H; the off-grid planner keeps
+# Round-4 call G (run twice: after calls F / H, and again as THE closing run after call I changed 12 more rows): the FINAL tree (family r's plan flags
+# in the table after calls F / H, the worst rows of the first closing report re-tuned in call I; the off-grid planner keeps
 # stream-K corner plans as such).  Full exact check (the log names geometries and forms), the whole `-m gpu` suite with its grid
 # passes kept as THE parity / tolerance records of the shipped table, smoke, the device-clock plan reports of the final table (grid
 # isolated + back to back, off-grid), the per-geometry PMC table of the final table, and the reference-metric records of the rows

@@ -42,6 +42,8 @@ def main(argv=None) -> int:
     ap.add_argument("--require-shipped", action="store_true", help="only touch shapes whose shipped plan was measured in the same run (a run "
                     "that times one family's plans says nothing about a row that ships another family's)")
     ap.add_argument("--report", default="", help="write the list of changed rows (JSON lines)")
+    ap.add_argument("--exclude", action="append", default=[], help="M_N_K:config:splits -- a candidate not to adopt although it measured fastest "
+                    "(e.g. a one-tile-per-CU lock-step plan whose time is known to depend on the box, DESIGN.md section 4.12)")
     a = ap.parse_args(argv)
     ok = set()
     for line in open(a.verified):
@@ -68,7 +70,9 @@ def main(argv=None) -> int:
             ship_us = next((c["us"] for c in cands if (c["config"], int(c["splits"]), int(c["group_m"])) == shipped), None)
             if ship_us is None:   # the same geometry and form with another raster group stands in for it (one tile row: the group is moot)
                 ship_us = next((c["us"] for c in cands if (c["config"], int(c["splits"])) == shipped[:2]), None)
-            pick = next((c for c in cands if (mnk, c["config"], int(c["splits"]), int(c["group_m"])) in ok), None)
+            barred = {tuple(x.split(":")) for x in a.exclude}
+            pick = next((c for c in cands if (mnk, c["config"], int(c["splits"]), int(c["group_m"])) in ok
+                         and (mnk, c["config"], str(int(c["splits"]))) not in barred), None)
             if pick is None or (pick["config"], int(pick["splits"]), int(pick["group_m"])) == shipped:
                 continue
             if ship_us is None and a.require_shipped:

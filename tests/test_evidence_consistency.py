@@ -102,7 +102,8 @@ def test_off_grid_report_and_parity_records():
         recs = _recs(PKG / "tuning" / name)
         assert len(recs) == 160 and all(r["pass"] for r in recs), name
     cand = sum(len(_recs(PKG / "tuning" / f)) for f in ("r04_candidate_parity_pass1.jsonl", "r04_candidate_parity_pass2.jsonl",
-                                                         "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl"))
+                                                         "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl",
+                                                         "r04_candidate_parity_worst_rows.jsonl"))
     assert f"{cand} candidate checks" in (REPO / "README.md").read_text()
     log = (REPO / "profiles" / "r04_check_final.log").read_text()
     runs = re.search(r"check: (\d+) runs, 0 failures", log)

@@ -275,7 +275,8 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
     ok = set()
     # (round 3's table + the two passes of the round-4 re-tune, tools/update_tuned_table.py --verified)
     for name in ("r03_candidate_parity.jsonl", "r04_candidate_parity_pass1.jsonl", "r04_candidate_parity_pass2.jsonl",
-                 "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl"):
+                 "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl",
+                 "r04_candidate_parity_worst_rows.jsonl"):
         for ln in (PKG / "tuning" / name).read_text().splitlines():
             r = json.loads(ln)
             if r["pass"] and r["bitwise_equal_unmasked"] and r["guard_bars_intact"] and r["max_diff_masked"] == 0.0:
