@@ -264,7 +264,11 @@ double model_us_streamk(const KernelEntry& e, int M, int N, int K, int G) {
 
 // K the geometry accepts: a multiple of its stage depth, or any multiple of 8 for the families that zero-fill a
 // partial last K-step themselves
-inline bool k_ok(const KernelEntry& e, int K) { return K % e.kgran == 0 || (e.ktail && K % 8 == 0); }
+// ... (classic family: the last LDS-DMA step is padded, so its step count rounds up), or accumulate the remainder from
+// fragments loaded straight from global memory behind at least one whole stage (families q and r, "direct" tail: the step
+// count rounds down and the remainder rides on the last split)
+inline bool direct_tail(const KernelEntry& e) { return e.ktail && e.name[0] != 't'; }
+inline bool k_ok(const KernelEntry& e, int K) { return K % e.kgran == 0 || (e.ktail && K % 8 == 0 && (!direct_tail(e) || K >= e.kgran)); }
 
 void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   double best = 1e30;
@@ -329,7 +333,8 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     if ((e.bm > M * 2 && e.bm > 32) || (e.bn > N * 2 && e.bn > 32)) continue;   // mostly padding
     const int ksteps = std::max(1, K / e.kgran);
     // a stream-K corner plan keeps its form (the low bits are its workgroup count, not a split count) and is priced as such
-    if ((p->splits & HGEMM_PLAN_STREAMK) && e.sk_wgs_per_cu > 0) {
+    const bool sk_usable = e.sk_wgs_per_cu > 0 && !(direct_tail(e) && K % e.kgran != 0);   // (no stream-K kernel with a direct tail)
+    if ((p->splits & HGEMM_PLAN_STREAMK) && sk_usable) {
       const double t = model_us_streamk(e, M, N, K, streamk_grid(e, p->splits & HGEMM_SPLITK_MASK));
       if (t < best) {
         best = t; found = true;
@@ -339,7 +344,7 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       }
       continue;
     }
-    const int s = std::max(1, std::min(p->splits & HGEMM_SPLITK_MASK, ksteps));
+    const int s = (p->splits & HGEMM_PLAN_STREAMK) ? 1 : std::max(1, std::min(p->splits & HGEMM_SPLITK_MASK, ksteps));
     // the 8-wave mid tiles were tuned (and the model fitted) for at most two workgroups per CU: beyond that the larger tiles of
     // another corner win (1332 x 3108 x 4440: 525 tiles of 64 x 128 measured 101 us against 82 us for the 256 x 256 corner plan)
     if (e.name[0] == 't' && e.wm * e.wn == 8 && e.bm * e.bn <= 128 * 64 &&
@@ -358,7 +363,7 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   // persistent tiles although they may fit it exactly (3072^2: 144 tiles of 256 x 256 on 256 CUs, 192 of 192 x 256).  They join the
   // ranking with the split count of the best corner and unsplit (the model prices the members of family q on one scale:
   // measured / modelled 1.39-1.42 for all of them, tuning/r03_late_tune_mi355x.jsonl).
-  if (found && K % 64 == 0) {
+  if (found) {
     const int best_s = (*splits & HGEMM_PLAN_STREAMK) ? 1 : std::max(1, *splits & HGEMM_SPLITK_MASK), best_fused = *splits & HGEMM_SPLITK_FUSED;
     const char* extra[2] = {(M % 192 == 0 && N >= 128) ? "q192x256_w2x2" : nullptr,
                             (N % 192 == 0 && M >= 128) ? "q256x192_w2x2" : nullptr};
@@ -368,7 +373,7 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       if (c < 0) continue;
       const KernelEntry& e = g_kernel_table[c];
       // (only where the 192-wide tiles fill at least half the chip: 1968 x 576 has 24 of them and measured 0.72x of its corner plan)
-      if ((long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) < kCUs / 2) continue;
+      if ((long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) < kCUs / 2 || !k_ok(e, K)) continue;
       for (int s : {1, best_s}) {
         if (s > std::max(1, K / e.kgran)) continue;
         const double t = model_us(e, M, N, K, s);
@@ -429,6 +434,11 @@ int hgemm_mi355x_config_info(int id, int out[8]) {
 int hgemm_mi355x_config_k_granularity(int id) {
   if (id < 0 || id >= g_num_kernels) return 1;
   return g_kernel_table[id].ktail ? 8 : g_kernel_table[id].kgran;
+}
+
+int hgemm_mi355x_config_accepts_k(int id, int K) {
+  if (id < 0 || id >= g_num_kernels) return K > 0 ? 1 : 0;   // the special ids take any K
+  return K > 0 && k_ok(g_kernel_table[id], K) ? 1 : 0;
 }
 
 int hgemm_mi355x_config_by_name(const char* name) {
@@ -583,7 +593,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     const KernelEntry& e = g_kernel_table[config_id];
     const double reach = e.ktail ? 2147483648.0 : 4294967296.0;   // (the classic family keeps bit 31 as its out-of-range mark)
     if ((double)e.bm * lda * 2.0 + K * 2.0 >= reach || (double)e.bn * ldb * 2.0 + K * 2.0 >= reach) fast = false;
-    if (K % BK != 0 && !e.ktail) fast = false;   // a partial last K-step on a geometry that cannot pad it: any-shape kernel
+    if (K % BK != 0 && !k_ok(e, K)) fast = false;   // a partial last K-step on a geometry that cannot take it: any-shape kernel
     // the LDS-staged epilogue addresses a wave tile through one buffer descriptor with 32-bit offsets
     if ((double)e.bm * ldc * 2.0 + (double)N * 2.0 >= 2147483648.0) fast = false;
   }
@@ -603,13 +613,14 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     // pipeline stages of this geometry along K (BK = 64, or 128 for the "_k128" members)
     if (!k_ok(e, K)) return HGEMM_ERR_BAD_ARG;
     const int kgran = e.kgran;
-    const int ksteps = (K + kgran - 1) / kgran;
+    const bool tail_direct = direct_tail(e) && K % kgran != 0;
+    const int ksteps = tail_direct ? K / kgran : (K + kgran - 1) / kgran;   // (direct tail: whole stages; the rest rides on the last split)
     // Stream-K (HGEMM_PLAN_STREAMK; the low bits of `splits` are then the number of persistent workgroups): one launch, no
     // combine kernel.  Not available (family without the kernel, too many tiles for the counter block, no workspace): the
     // plan degrades to the geometry's plain data-parallel launch, like a split-K plan without workspace.
     if (want_streamk) {
       const long total = tiles * ksteps;
-      if (e.sk_wgs_per_cu > 0 && tiles <= (long)kMaxFusedTiles && total < (1L << 30)) {
+      if (e.sk_wgs_per_cu > 0 && tiles <= (long)kMaxFusedTiles && total < (1L << 30) && !tail_direct) {   // (no stream-K kernel with a direct tail)
         const int min_steps = streamk_min_steps(e);
         const int G = (int)std::max<long>(1, std::min<long>(streamk_grid(e, splits), std::max<long>(1, total / min_steps)));
         const size_t slab_bytes = (size_t)2 * G * e.bm * e.bn * sizeof(float);

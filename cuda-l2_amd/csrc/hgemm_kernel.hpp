@@ -295,6 +295,10 @@ constexpr int EPI_C16    = 0;  // fp16 C, written directly (splits == 1)
 constexpr int EPI_SLAB   = 1;  // fp32 partials to [splits][M][N] (or compact tail slabs); a second kernel combines
 constexpr int EPI_FUSED  = 2;  // single-launch split-K: fp32 partials + arrival counter, the last arriver combines
 constexpr int EPI_STREAMK = 3; // stream-K: one persistent launch over the tile-major K-stage sequence (StreamK above)
+// Kernel-template flag on top of an epilogue id (families q and r): the "ktail" variant of the kernel, for a K that is not a
+// multiple of the geometry's stage depth -- whole stages through the pipeline, the rest by direct_k_tail.  A variant of its own,
+// so the kernels every K % stage == 0 launch runs keep their instruction streams.
+constexpr int EPI_KTAIL = 8;
 
 // Compile-time geometry of one kernel instantiation.
 template <int BM_, int BN_, int WM_, int WN_, int MI_, int NBUF_>
@@ -583,6 +587,67 @@ __device__ __forceinline__ void stage_tile_tail(__amdgpu_buffer_rsrc_t rsA, __am
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, vo, kbyte, 0, HGEMM_DMA_AUX);
     }
   }
+}
+
+
+// K tail by DIRECT fragment loads (families q and r, their "ktail" kernel variants; the classic family pads its last LDS-DMA
+// step instead, stage_tile_tail): the last k_end - k0 elements (> 0, a multiple of 8, less than one pipeline stage) of a work
+// item's K range never enter LDS.  Every wave loads the MFMA fragments of its own wave tile straight from global memory, the
+// way family w does for whole problems (hgemm_kernel_wd.hpp): lane l holds the 8 consecutive K of row l & 15 at
+// k = 8 (l >> 4) of a K = 32 slice, 16 rows x 64 contiguous bytes per wave instruction.  The reference pads K in the
+// harness instead (tools/utils.py:8-36).
+// The loads are buffer loads through descriptors that start at the tile's first row and end with the matrix (at most 2 GiB,
+// and every real offset below that: host check): rows past the M / N edge are out of range and read as zeros (their
+// products are never stored), and a lane whose 8 halfs lie at k >= k_end gets bit 31 into its offset -- out of range as
+// well, so the last, partial slice is zero-filled per lane (the mark of stage_tile_tail).  U slices, U (FM + FN) loads,
+// are in flight behind one wait.  mfma(i, j, b, a) accumulates the fragment pair of A row block i and B row block j.
+template <int FM, int FN, class F>
+__device__ __forceinline__ void direct_k_tail(const GemmArgs& g, int m0, int n0, int row_a, int row_b, int k0, int k_end, int lane,
+                                              F&& mfma) {
+  auto rsrc_of = [](const f16* base, size_t bytes) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
+    const uintptr_t uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
+    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0x80000000ull ? 0x80000000ull : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, nrec, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsA = rsrc_of(g.A + (size_t)m0 * g.lda, ((size_t)(g.M - m0) * g.lda) * 2);
+  const __amdgpu_buffer_rsrc_t rsB = rsrc_of(g.Bt + (size_t)n0 * g.ldb, ((size_t)(g.N - n0) * g.ldb) * 2);
+  const int l15 = lane & 15, lq = lane >> 4;
+  uint32_t va[FM], vb[FN];   // byte offset of this lane's row of every 16-row block of the wave tile
+#pragma unroll
+  for (int i = 0; i < FM; ++i) va[i] = (uint32_t)(row_a + i * 16 + l15) * (uint32_t)g.lda * 2u;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) vb[j] = (uint32_t)(row_b + j * 16 + l15) * (uint32_t)g.ldb * 2u;
+  const int nslices = (k_end - k0 + 31) / 32;
+  int s = 0;
+  auto trip = [&](auto u_tag) __attribute__((always_inline)) {
+    constexpr int U = decltype(u_tag)::value;
+    f16x8 af[U][FM], bf[U][FN];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (s + u) * 32 + lq * 8;
+      const uint32_t kb = k < k_end ? (uint32_t)k * 2u : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[u][i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA, va[i] + kb, 0, 0));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[u][j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, vb[j] + kb, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mfma(i, j, bf[u][j], af[u][i]);
+    s += U;
+  };
+  constexpr int UMAX = (FM + FN) <= 4 ? 4 : (FM + FN) <= 8 ? 2 : 1;   // at most 16 fragments (64 registers) per trip
+  if constexpr (UMAX > 1) {
+#pragma clang loop unroll(disable)
+    while (s + UMAX <= nslices) trip(std::integral_constant<int, UMAX>{});
+  }
+#pragma clang loop unroll(disable)
+  while (s < nslices) trip(std::integral_constant<int, 1>{});
 }
 
 #endif  // __HIP_DEVICE_COMPILE__

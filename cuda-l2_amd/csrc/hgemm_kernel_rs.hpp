@@ -272,11 +272,15 @@ __device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, i
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <class CFG, int EPI>
+// EPI_: EPI_C16 / EPI_SLAB / EPI_FUSED, + EPI_KTAIL: the variant for K % BKS != 0 (K % 8 == 0): the stage loop walks the whole
+// stages of the work item (the last split runs to K), the remaining < BKS elements are accumulated by direct_k_tail.
+template <class CFG, int EPI_>
 // two workgroups per CU wherever the tile allows it (second argument = waves per SIMD: <= 256 registers)
 __global__ void __launch_bounds__(CFG::THREADS, CFG::WGS_PER_CU) hgemm_tn_rs_kernel(const GemmArgs g) {
   prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int EPI = EPI_ & 7;
+  constexpr bool KTAIL = (EPI_ & EPI_KTAIL) != 0;
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, BKS = CFG::BKS;
 
   __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES];
@@ -287,11 +291,20 @@ __global__ void __launch_bounds__(CFG::THREADS, CFG::WGS_PER_CU) hgemm_tn_rs_ker
   const int wave_m = wave / CFG::WN, wave_n = wave % CFG::WN;
 
   const TileCoord tc = map_block(g, BM, BN);
-  const int nk = tc.nk / (BKS / BK);          // stages of this work item (host: K chunk % BKS == 0)
+  // K range of this work item; ktail variant: the host counts chunks on floor(K / BKS), the remainder rides on the last split
+  const int k_items = (KTAIL && tc.split + 1 == g.splits ? g.K : min(g.K, tc.k_begin + g.k_chunk)) - tc.k_begin;
+  const int nk = KTAIL ? k_items / BKS : tc.nk / (BKS / BK);   // whole stages (host: K chunk % BKS == 0)
   const unsigned tile_id = (unsigned)(tc.m0 / BM) + (unsigned)(tc.n0 / BN) * (unsigned)g.tiles_m + (unsigned)tc.split * 5u;
 
   f32x4 acc[FM][FN];
   rs_mainloop<CFG>(g, tc.m0, tc.n0, tc.k_begin, nk, tile_id, smem, tid, lane, wave_m, wave_n, acc);
+  if constexpr (KTAIL) {
+    if (nk * BKS < k_items)   // (workgroup-uniform)
+      direct_k_tail<FM, FN>(g, tc.m0, tc.n0, wave_m * CFG::TM, wave_n * CFG::TN, tc.k_begin + nk * BKS, tc.k_begin + k_items, lane,
+                            [&](int i, int j, const f16x8& b, const f16x8& a) __attribute__((always_inline)) {
+                              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc[i][j], 0, 0, 0);
+                            });
+  }
 
   if constexpr (EPI == EPI_FUSED) __syncthreads();   // the vote word lives at smem[0]: every wave must be done reading
   classic_epilogue<CFG, EPI>(g, tc, acc, smem, tid, lane, wave_m, wave_n);

@@ -375,7 +375,8 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
       nxt_item = (ITEM);                                                                                       \
       nxt_m0 = __builtin_amdgcn_readfirstlane(itc.m0); nxt_n0 = __builtin_amdgcn_readfirstlane(itc.n0);        \
       nxt_kb = __builtin_amdgcn_readfirstlane(itc.k_begin * 2);                                                \
-      nxt_nk = __builtin_amdgcn_readfirstlane(itc.nk / CFG::KT);   /* stages of K = 64 * KT (host: K chunk % (64 KT) == 0) */ \
+      /* stages of K = 64 * KT (host: K chunk % (64 KT) == 0); ktail variant: WHOLE stages of the item's K range */       \
+      nxt_nk = __builtin_amdgcn_readfirstlane(KTAIL ? sq_k_items(g, itc) / (BK * CFG::KT) : itc.nk / CFG::KT);           \
     }                                                                                                          \
     const uintptr_t addr = (OP) == 0 ? reinterpret_cast<uintptr_t>(g.A + (size_t)nxt_m0 * g.lda)               \
                                      : reinterpret_cast<uintptr_t>(g.Bt + (size_t)nxt_n0 * g.ldb);             \
@@ -431,11 +432,25 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
     ++step;                                                                                                     \
   } while (0)
 
-// EPI: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB / SP_EPI_FUSED (as family "s")
-template <class CFG, int EPI>
+// K range of a work item in the ktail variant: the LAST split runs to K (the host cuts K into chunks of whole stages, counted
+// on floor(K / stage): the remainder rides on the last split)
+__device__ __forceinline__ int sq_k_items(const GemmArgs& g, const TileCoord& tc) {
+  return (tc.split + 1 == g.splits ? g.K : tc.k_begin + g.k_chunk) - tc.k_begin;
+}
+
+// EPI_: SP_EPI_NARROW / SP_EPI_WIDE / SP_EPI_SLAB / SP_EPI_FUSED (as family "s"), + EPI_KTAIL: the variant for K % (64 KT) != 0
+// (K % 8 == 0, MI = 16 members): the pipeline walks the whole stages of every work item, the remaining < 64 KT elements are
+// accumulated by direct_k_tail between the item's last K-step and its epilogue.  At that point the fragment sets X, Y, U
+// already hold the NEXT item's first tile (the streams cross item seams), Z and V are dead: the tail's fragments take their
+// registers.  Its loads queue behind the LDS-DMA pieces in flight; waiting for them (vmcnt is in order) only lands the
+// next item's tiles early.
+template <class CFG, int EPI_>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
   prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int EPI = EPI_ & 7;
+  constexpr bool KTAIL = (EPI_ & EPI_KTAIL) != 0;
+  static_assert(!KTAIL || CFG::MI == 16, "the K tail is built from 16x16x32 fragments");
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ, MI = CFG::MI;
   constexpr int NFA = CFG::NFA, NFB = CFG::NFB;
   constexpr int NQ = CFG::ACC / 4;              // f32x4 quads per accumulator tile
@@ -544,7 +559,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma clang loop unroll(disable)
   for (int item = 0; item < walk.count; ++item) {
     const TileCoord tc = map_logical(g, walk.base + walk.first + item * walk.stride, BM, BN);
-    const int nk = __builtin_amdgcn_readfirstlane(tc.nk / CFG::KT);
+    const int nk = __builtin_amdgcn_readfirstlane(KTAIL ? sq_k_items(g, tc) / (BK * CFG::KT) : tc.nk / CFG::KT);
     HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 3, tid);
     // hot loop, two K-steps per trip: both streams stay inside this work item (in K-step t the A stream moves on to tile
     // t+3 and the B stream to tile t+3 behind it: the trip's last move, to t+4, must stay inside the item; t + 5 < nk keeps
@@ -574,6 +589,15 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
 #pragma unroll
       for (int r = 0; r < NFA; ++r) fY[r] = fZ[r];
       sq_settle(fX, fY, fU);
+    }
+    if constexpr (KTAIL) {
+      const int k_items = sq_k_items(g, tc), k_full = nk * (BK * CFG::KT);
+      if (k_full < k_items) {   // (wave-uniform)
+        __builtin_amdgcn_sched_barrier(0);
+        direct_k_tail<FM, FN>(g, tc.m0, tc.n0, wave_m * CFG::TM, wave_n * CFG::TN, tc.k_begin + k_full, tc.k_begin + k_items, lane,
+                              [](int i, int j, const f16x8& b, const f16x8& a) __attribute__((always_inline)) { sp_mfma(i * FN + j, b, a); });
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // ---- epilogue of this work item (as family "s"): unit by unit (MI = 16: one fragment row, MI = 32: one tile) ---
     HGEMM_TL_STAMP(smem + CFG::LDS_BYTES, 4, tid);

@@ -69,6 +69,19 @@ void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
 template <class CFG>
 void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
   const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  if constexpr (CFG::MI == 16) {
+    if (g.K % (BK * CFG::KT) != 0) {   // the ktail variants (hgemm_kernel_sq.hpp): whole stages + a direct tail
+      if (epi == EPI_FUSED)
+        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+      else if (epi == EPI_SLAB)
+        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+      else if (wide)
+        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+      else
+        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+      return;
+    }
+  }
   if (epi == EPI_FUSED)
     HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
   else if (epi == EPI_SLAB)
@@ -81,6 +94,15 @@ void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
 
 template <class CFG>
 void launch_rs(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
+  if (g.K % CFG::BKS != 0 && epi != EPI_STREAMK) {   // the ktail variants (the host never asks for stream-K with a K tail)
+    if (epi == EPI_FUSED)
+      HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_FUSED | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+    else if (epi == EPI_SLAB)
+      HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+    else
+      HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_C16 | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
+    return;
+  }
   if (epi == EPI_STREAMK)
     HGEMM_LAUNCH((hgemm_tn_rs_sk_kernel<CFG>), grid, CFG::THREADS, stream, ts, g);
   else if (epi == EPI_FUSED)
@@ -110,7 +132,9 @@ struct KernelEntry {
   bool has_fused;      // the family has a single-launch split-K epilogue (EPI_FUSED)
   int kgran;           // K granularity of one pipeline stage (64, or 128 / 256 for the deep-stage members): every
                        // split-K chunk is a multiple, and so is K unless `ktail`
-  bool ktail;          // the kernel zero-fills a partial last K-step by itself: any K % 8 == 0 is accepted
+  bool ktail;          // the kernel takes a K that is not a multiple of kgran (K % 8 == 0): the classic family zero-fills a partial
+                       // last LDS-DMA step; families q (MI = 16) and r run their "ktail" variants: whole stages through the
+                       // pipeline (so K >= kgran), the rest from fragments loaded straight from global memory (direct_k_tail)
   int sk_wgs_per_cu;   // > 0: the family has a stream-K kernel (EPI_STREAMK); workgroups of it one CU holds (default G = 256 x this)
 };
 

@@ -74,7 +74,7 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)                                                                     \
   {HGEMM_SQ_NAME_##KT##_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2, CfgSQ<BM, BN, WM, WN, KT, MI>::THREADS,      \
    CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>,                      \
-   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64)), true, 64 * KT, false, 0},
+   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64)), true, 64 * KT, MI == 16, 0},
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP
@@ -87,7 +87,7 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_RS_SUFFIX_2 "_d"
 #define HGEMM_RS(G, BM, BN, BKS, LB)                                                                                   \
   {"r" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_k" HGEMM_STR(BKS) HGEMM_RS_SUFFIX_##LB, BM, BN, 2, 2, 16, LB, CfgRS<BM, BN, BKS, LB>::THREADS, \
-   CfgRS<BM, BN, BKS, LB>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS, LB>>, 0, true, BKS, false, CfgRS<BM, BN, BKS, LB>::WGS_PER_CU},
+   CfgRS<BM, BN, BKS, LB>::LDS_BYTES, &launch_rs<CfgRS<BM, BN, BKS, LB>>, 0, true, BKS, true, CfgRS<BM, BN, BKS, LB>::WGS_PER_CU},
 #include "hgemm_configs.def"
 #undef HGEMM_RS
 #undef HGEMM_WD

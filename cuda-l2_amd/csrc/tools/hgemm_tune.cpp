@@ -230,7 +230,7 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
       continue;
     if (info[0] > sh.M * 2 && info[0] > 32) continue;
     if (info[1] > sh.N * 2 && info[1] > 32) continue;
-    if (sh.K % hgemm_mi355x_config_k_granularity(c) != 0) continue;
+    if (!hgemm_mi355x_config_accepts_k(c, sh.K)) continue;
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && ksteps / s < 2) break;
       const long wgs = (long)((sh.M + info[0] - 1) / info[0]) * ((sh.N + info[1] - 1) / info[1]) * s;
@@ -427,7 +427,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       auto it = g_cand_file.find(key);
       if (it != g_cand_file.end())
         for (Plan p : it->second) {
-          if (sh.K % hgemm_mi355x_config_k_granularity(p.cfg) != 0) continue;
+          if (!hgemm_mi355x_config_accepts_k(p.cfg, sh.K)) continue;
           p.model_us = hgemm_mi355x_model_us(p.cfg, p.splits, sh.M, sh.N, sh.K);   // (takes `splits` as the launch does)
           cands.push_back(p);
         }
@@ -878,8 +878,11 @@ int main(int argc, char** argv) {
   }
   if (mode == "check") {
     if (shapes.empty())
+      // (the last two: K tails -- 2104 = 32 x 64 + 56 = 8 x 256 + 56, 728 = 11 x 64 + 24 = 5 x 128 + 88 = 2 x 256 + 216: odd and even
+      // stage counts, one to seven K = 32 slices of tail, the last one partial.  The tail at the item seams of a persistent walk
+      // needs more items than resident workgroups: `check --shapes 4352_4352_328 --configs <family q>`, tools/lab/gpu_round4_j.sh)
       shapes = parse_shapes("64_64_64,64_4096_64,128_192_256,200_136_128,256_256_1024,320_448_512,512_1024_2048,1000_520_192,"
-                            "1000_520_200,65_30_100,33_17_40,300_260_2048");
+                            "1000_520_200,65_30_100,33_17_40,300_260_2048,300_260_2104,520_392_728");
     return cmd_check(shapes);
   }
   if (mode == "tune") {

@@ -139,11 +139,18 @@ const char* hgemm_mi355x_config_name(int config_id);
 /* out[0..7] = BM, BN, WM, WN, MI, NBUF, threads, lds_bytes */
 int hgemm_mi355x_config_info(int config_id, int out[8]);
 int hgemm_mi355x_config_by_name(const char* name);
-/* The K multiple a geometry accepts: 8 for the classic "t" family (it zero-fills a partial last K-step itself), the
- * pipeline stage depth for the others (64; 128 / 256 for the "_k128" / "_k256" members).  hgemm_mi355x_launch
- * returns HGEMM_ERR_BAD_ARG for a table geometry when K is not a multiple (the planner never picks one); 1 for
- * the special ids. */
+/* The K multiple a geometry accepts: 8 for the families that take a K tail -- the classic "t" family zero-fills a partial
+ * last K-step itself; families "q" (16x16x32 members) and "r" run the whole pipeline stages and accumulate the remainder
+ * from fragments loaded straight from global memory (round 4; K must then hold at least one whole stage:
+ * hgemm_mi355x_config_accepts_k) -- and the pipeline stage depth for the others (64; the reference pads K in the
+ * harness instead, tools/utils.py:8-36).  hgemm_mi355x_launch returns HGEMM_ERR_BAD_ARG for a table geometry when K is a
+ * multiple of 64 but not of its stage depth, and serves any other K it cannot take with the any-shape kernel (the planner
+ * never picks such a geometry); 1 for the special ids. */
 int hgemm_mi355x_config_k_granularity(int config_id);
+/* 1 when hgemm_mi355x_launch runs this geometry's own kernel for a problem with this K (operands aligned), 0 when it
+ * would fall back or refuse: K a multiple of the stage depth, or K % 8 == 0 on a geometry with a K tail (families q and
+ * r: K >= one stage). */
+int hgemm_mi355x_config_accepts_k(int config_id, int K);
 /* > 0 when the geometry has a stream-K kernel (HGEMM_PLAN_STREAMK): workgroups of it one CU holds. */
 int hgemm_mi355x_config_streamk(int config_id);
 

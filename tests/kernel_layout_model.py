@@ -123,10 +123,14 @@ def bank_conflict_extra_cycles(byte_addrs) -> int:
     return extra
 
 
-def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int, oob_zero: bool = False):
-    """Compute the C tile at (m0, n0) the way the kernel does. Returns (C_tile dict, conflicts)."""
+def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int, oob_zero: bool = False, k_whole: int = -1, extra_acc=None):
+    """Compute the C tile at (m0, n0) the way the kernel does. Returns (C_tile dict, conflicts).
+    k_whole >= 0: only the first k_whole (a multiple of 64) elements of K go through the pipeline; extra_acc: accumulators of
+    the same layout added before the epilogue (the "ktail" kernel variants: whole stages + direct_k_tail)."""
     M, K = A.shape
     N = Bt.shape[0]
+    if k_whole >= 0:
+        K = k_whole
     assert K % BK == 0
     # tile-local views with clamped rows handled inside stage_tile
     a_tile = A[m0:]
@@ -155,6 +159,8 @@ def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int, oob
                 for i in range(geo.FM):
                     for j in range(geo.FN):
                         acc[wave, i, j] += mfma(mi, bf[j], af[i])  # operands swapped, as in the kernel
+    if extra_acc is not None:
+        acc += extra_acc
     # epilogue mapping
     out = {}
     for wave in range(geo.NW):
@@ -174,6 +180,45 @@ def run_tile(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int, oob
                                 assert key not in out, "two lanes write the same C element"
                                 out[key] = acc[wave, i, j, lane, q * 4 + e]
     return out, conflicts
+
+
+def direct_k_tail(geo: Geometry, A: np.ndarray, Bt: np.ndarray, m0: int, n0: int, k0: int, k_end: int):
+    """The K tail of families q and r (hgemm_kernel.hpp: direct_k_tail), restated on byte offsets: every wave loads the MFMA
+    fragments of its wave tile straight from the operands through a descriptor that starts at the tile's first row and ends
+    with the matrix (at most 2 GiB); lane l reads the 16 bytes at ((row block i * 16 + l & 15) * ld + k) * 2 with
+    k = k0 + 32 s + 8 (l >> 4), or at that + 2^31 when k >= k_end.  An offset at or beyond the range reads zeros.
+    Returns acc[wave][i][j][lane][4] (MI = 16 members only), to be added to the pipeline's accumulators."""
+    assert geo.MI == 16 and k_end > k0 and (k_end - k0) % 8 == 0
+    (M, lda), (N, ldb) = A.shape, Bt.shape
+    flat_a, flat_b = A.reshape(-1), Bt.reshape(-1)
+
+    def load(flat, base_elems, range_bytes, off_bytes):
+        if off_bytes >= min(range_bytes, 1 << 31):
+            return np.zeros(8)
+        assert off_bytes % 16 == 0 and off_bytes + 16 <= range_bytes, "a real offset must stay inside the operand"
+        e = base_elems + off_bytes // 2
+        return flat[e:e + 8]
+
+    acc = np.zeros((geo.NW, geo.FM, geo.FN, 64, 4))
+    range_a, range_b = (M - m0) * lda * 2, (N - n0) * ldb * 2
+    nslices = (k_end - k0 + 31) // 32
+    for wave in range(geo.NW):
+        row_a, row_b = (wave // geo.WN) * geo.TM, (wave % geo.WN) * geo.TN
+        for s_ in range(nslices):
+            af = [np.zeros((64, 8)) for _ in range(geo.FM)]
+            bf = [np.zeros((64, 8)) for _ in range(geo.FN)]
+            for lane in range(64):
+                l15, lq = lane & 15, lane >> 4
+                k = k0 + s_ * 32 + lq * 8
+                kb = k * 2 if k < k_end else 1 << 31
+                for i in range(geo.FM):
+                    af[i][lane] = load(flat_a, m0 * lda, range_a, (row_a + i * 16 + l15) * lda * 2 + kb)
+                for j in range(geo.FN):
+                    bf[j][lane] = load(flat_b, n0 * ldb, range_b, (row_b + j * 16 + l15) * ldb * 2 + kb)
+            for i in range(geo.FM):
+                for j in range(geo.FN):
+                    acc[wave, i, j] += mfma(16, bf[j], af[i])
+    return acc
 
 
 def remap_block(bid: int, nwg: int) -> int:

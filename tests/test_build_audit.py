@@ -40,8 +40,13 @@ def _compile_groups(tmp_path_factory, opt: str) -> str:
 
 
 @pytest.fixture(scope="module")
-def sp_functions(tmp_path_factory):
-    text = _compile_groups(tmp_path_factory, "-O3")
+def isa_text(tmp_path_factory):
+    return _compile_groups(tmp_path_factory, "-O3")
+
+
+@pytest.fixture(scope="module")
+def sp_functions(isa_text):
+    text = isa_text
     funcs = {}
     for m in re.finditer(r"^(_ZN12hgemm_mi355x18hgemm_tn_s[pq]_kernel\w+):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
         funcs[m.group(1)] = m.group(2).splitlines()
@@ -84,8 +89,10 @@ def test_sp_kernels_do_not_spill_and_leave_room_for_the_agprs(sp_functions):
         # (2) >= 16; only the single-launch split-K form (3: fragments + a combine row live together) may use the file
         # up to the last register -- a compiler bump that costs one more there fails the 256-AGPR check above instead of
         # silently spilling.  The table is printed (pytest -s / on failure) so a creeping allocation is visible early.
-        epi = int(re.search(r"ELi(\d)EEEvNS", name).group(1))
-        bound = {0: 224, 1: 224, 2: 240, 3: 256}[epi]
+        # (family q's "ktail" variants carry EPI_KTAIL = 8 on top of the epilogue id: same classes, same bounds -- the tail's
+        # fragments live in the registers of the two fragment sets that are dead at an item's end)
+        epi = int(re.search(r"ELi(\d+)EEEvNS", name).group(1))
+        bound = {0: 224, 1: 224, 2: 240, 3: 256}[epi & 7]
         print(f"accum_offset {accum.group(1):>3} (bound {bound})  {name}")
         assert int(accum.group(1)) <= bound, f"{name}: {accum.group(1)} VGPRs > {bound} (epilogue class {epi})"
 
@@ -143,6 +150,8 @@ def test_m0_writes_and_lds_dma_loads_alternate_in_the_k_loops(sp_functions):
                 elif code.startswith("v_mfma_") and events and events[-1] == "m0":
                     events.append("mfma")
             seq = [e for e in events if e != "mfma"]
+            if not seq and int(re.search(r"ELi(\d+)EEEvNS", name).group(1)) & 8:
+                continue   # the slice loop of a ktail variant's direct tail: MFMAs on fragments from plain buffer loads, no LDS-DMA
             assert seq and seq[0] == "m0" and seq[-1] == "dma", f"{name}: {seq[:4]} ... {seq[-4:]}"
             assert all(a != b for a, b in zip(seq, seq[1:])), f"{name}: M0 writes and LDS-DMA loads do not alternate"
             # an MFMA between every M0 write and its load
@@ -434,3 +443,36 @@ def test_the_audits_hold_at_a_second_optimisation_level(tmp_path_factory):
         assert not [ln for ln in _outside_asm(lines) if re.search(r"\bv_accvgpr_|\bv_mfma_|\ba\[?\d+", ln.split(";")[0])], name
         if "sq_kernel" in name:
             assert not m0_provenance_violations(lines), name
+
+
+def test_kernels_of_the_measured_library_keep_their_instruction_streams(isa_text):
+    """Round 4 added kernels (the "ktail" variants of families q and r) AFTER the closing run had measured the library.  The grid
+    records of round 4 (plan reports, sweeps, PMC table, bench) stay valid only if the kernels they ran are untouched, and "I did
+    not edit that function" is not evidence: the new variants are instantiations of the same templates and share non-inlined
+    helpers with them.  So: every kernel of the closing run's library (profiles/r04_isa_fingerprint_closing_run_library.json, made
+    by tools/isa_fingerprint.py from the sources of that commit) still exists, and its instruction stream is the same modulo
+    basic-block numbering -- except the ones listed here with the reason, none of which a shipped grid plan can launch."""
+    import json
+    import sys
+
+    sys.path.insert(0, str(REPO / "cuda-l2_amd" / "tools"))
+    import isa_fingerprint
+
+    base = json.loads((REPO / "profiles" / "r04_isa_fingerprint_closing_run_library.json").read_text())["kernels"]
+    now = isa_fingerprint.fingerprints(isa_text)
+    assert len(base) == 232 and not set(base) - set(now), sorted(set(base) - set(now))[:3]
+    changed = sorted(k for k in base if now[k] != base[k])
+    # The 128 x 256 members of families s and q, narrow (0) / slab (2, s only) / fused (3) epilogues: their epilogue helper
+    # (store_tile_row for FN = 8, 64 x 128 wave tiles) gained callers in q128x256's ktail variants and hipcc now hoists its column
+    # offsets differently; the K loops differ in register numbers only.  Grid shapes never launch them: N % 8 == 0 takes the wide
+    # epilogue, no s128x256 row ships, and no q128x256 row is single-launch split-K (checked below on the table).
+    allowed = {k for k in base if re.search(r"Cfg(SP|SQ)ILi128ELi256ELi2ELi2E(Li1E)?Li16EEELi[023]E", k)}
+    assert set(changed) <= allowed, [k for k in changed if k not in allowed][:5]
+    assert len(changed) <= 5, changed
+    rows = re.findall(r'\{\d+, \d+, \d+, "(\w+)", (\d+), \d+\}', (CSRC / "hgemm_tuned_table.inc").read_text())
+    assert len(rows) == 1000
+    assert not [r for r in rows if r[0].startswith("s128x256")]
+    assert not [r for r in rows if r[0] == "q128x256_w2x2" and int(r[1]) & 0x10000]
+    # ... and the additions are what this change set out to add: ktail variants (epilogue id + 8) of families q and r
+    added = sorted(set(now) - set(base))
+    assert added and all(re.search(r"hgemm_tn_(sq|rs)_kernel.*ELi(8|9|10|11)EEEvNS", k) for k in added), added[:3]

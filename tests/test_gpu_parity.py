@@ -160,34 +160,36 @@ def ctypes_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def test_special_values_round_like_the_reference(g):
+@pytest.mark.parametrize("k,hot", [(512, 300), (552, 540)])
+def test_special_values_round_like_the_reference(g, k, hot):
     """The epilogue's fp32 -> fp16 conversion and the non-finite / denormal paths, which 0/1 inputs (values <= 2047, exact in every
     rounding mode) cannot see: the result must equal the reference's oracle expression (a.float() @ b.float()).half()
     (zero_one_correctness_check.py:85-90) -- round-to-nearest-even incl. overflow to inf at 65520, ties to even at the bottom
     of the denormal range, inf / NaN propagation (inf x 0, inf - inf), denormal operands and results -- for every kernel
     family, both split-K forms (the slabs carry inf / NaN / denormals in fp32) and stream-K.  Every row's sum is exact in fp32
-    whatever the summation order."""
-    m, n, k = 128, 192, 512
+    whatever the summation order.  Second case: K = 552 = 8 x 64 + 40 with the second hot column inside the K tail, so the
+    "ktail" variants of families q and r (and the classic family's padded last step) carry inf / NaN / denormals through their tails."""
+    m, n = 128, 192
     a = torch.zeros((m, k), dtype=torch.half)
     b = torch.zeros((k, n), dtype=torch.half)
-    b[0, :] = 1.0; b[1, :] = 1.0; b[300, :] = 1.0
+    b[0, :] = 1.0; b[1, :] = 1.0; b[hot, :] = 1.0
     b[0, 5::7] = 0.0                                  # columns where an inf in A meets a zero in B
     b[2, :] = 2.0 ** -10
     inf = float("inf")
     a[0, 0] = 65504.0                                  # the largest finite value survives
-    a[1, 1] = 65504.0; a[1, 300] = 16.0                # 65520: the tie between 65504 and 2^16 rounds to even = inf
-    a[2, 0] = 65504.0; a[2, 300] = 8.0                 # 65512 rounds down to 65504
+    a[1, 1] = 65504.0; a[1, hot] = 16.0                # 65520: the tie between 65504 and 2^16 rounds to even = inf
+    a[2, 0] = 65504.0; a[2, hot] = 8.0                 # 65512 rounds down to 65504
     a[3, 0] = -65504.0; a[3, 1] = -16.0                # -inf
     a[4, 0] = inf                                      # inf, and NaN where B has a zero
-    a[5, 1] = inf; a[5, 300] = -inf                    # inf - inf = NaN
-    a[6, 300] = float("nan")                           # NaN x anything
+    a[5, 1] = inf; a[5, hot] = -inf                    # inf - inf = NaN
+    a[6, hot] = float("nan")                           # NaN x anything
     a[7, 1] = 2.0 ** -24                               # a denormal operand, a denormal result
     a[8, 2] = 2.0 ** -14                               # 2^-14 x 2^-10 = 2^-24: a denormal result from normal operands
     a[9, 2] = 2.0 ** -15                               # 2^-25: the tie between 0 and 2^-24 rounds to even = 0
     a[10, 2] = 1.5 * 2.0 ** -15                        # 1.5 x 2^-25 rounds up to 2^-24
-    a[11, 1] = 1.0; a[11, 300] = 2.0 ** -11            # 1 + 2^-11: tie, rounds to even = 1
-    a[12, 1] = 1.0; a[12, 300] = 3 * 2.0 ** -11        # 1 + 3 x 2^-11: tie, rounds to even = 1 + 2^-9
-    a[13, 1] = 2048.0; a[13, 300] = 1.0                # 2049 -> 2048 (the first integer fp16 cannot hold)
+    a[11, 1] = 1.0; a[11, hot] = 2.0 ** -11            # 1 + 2^-11: tie, rounds to even = 1
+    a[12, 1] = 1.0; a[12, hot] = 3 * 2.0 ** -11        # 1 + 3 x 2^-11: tie, rounds to even = 1 + 2^-9
+    a[13, 1] = 2048.0; a[13, hot] = 1.0                # 2049 -> 2048 (the first integer fp16 cannot hold)
     a[14, 0] = 60000.0; a[14, 1] = 60000.0             # finite operands, overflowing sum
     a[64:, :] = a[:64, :].clone()                      # the same rows in the second 64-row band of every tile
     truth = (a.float() @ b.float()).half()
@@ -200,7 +202,8 @@ def test_special_values_round_like_the_reference(g):
     plans = [("entry fp32", None), ("entry fp16", None), ("ragged", (-2, 1, 1)), ("generic", (-1, 1, 1))]
     for cfg, splits in [("t64x64_w2x2_m16_s4", 1), ("t128x128_w2x2_m32_s2", 2), ("t128x128_w2x2_m16_s3", 2 | 0x10000), ("t64x64_w2x2_m16_s4", 0x40000 | 5),
                         ("s256x128_w2x2", 2), ("q128x128_w2x2", 1), ("q256x256_w2x2", 1 | 0x20000), ("q128x256_w2x2", 2 | 0x10000), ("q192x256_w2x2", 1),
-                        ("q256x256_w2x2_m32", 1), ("r64x64_k256", 1), ("r128x64_k128", 2 | 0x10000), ("r128x128_k128", 0x40000 | 3)]:
+                        ("q256x256_w2x2_m32", 1), ("r64x64_k256", 1), ("r128x64_k128", 2 | 0x10000), ("r128x128_k128", 0x40000 | 3),
+                        ("q128x128_w2x2_k128", 2), ("r64x128_k128_d", 1 | 0x180000)]:
         plans.append((f"{cfg}/{splits:#x}", (names.index(cfg), splits, 1)))
     for label, plan in plans:
         c = torch.full((m, n), 7.0, dtype=torch.half, device="cuda")
@@ -463,22 +466,29 @@ def test_ragged_kernel_and_reference_kernel_explicitly(g, oracle, shape):
     assert np.array_equal(got.view(np.uint16), truth.view(np.uint16))
 
 
-@pytest.mark.parametrize("shape", [(1000, 520, 200), (320, 448, 520), (200, 136, 1000), (4000, 520, 4008), (257, 1028, 72), (64, 64, 8)])
-def test_partial_last_k_step_of_the_classic_family(g, oracle, shape):
-    """K % 64 != 0, K % 8 == 0: the classic geometries zero-fill the partial last K-step through out-of-range DMA
-    lanes.  Every classic geometry x split-K form, plus the library's own plan, bit-exact; guard: NaN-prefilled C."""
+@pytest.mark.parametrize("shape", [(1000, 520, 200), (320, 448, 520), (200, 136, 1000), (4000, 520, 4008), (257, 1028, 72), (64, 64, 8),
+                                   (300, 260, 2104), (520, 392, 728)])
+def test_k_tail_of_every_geometry_that_takes_one(g, oracle, shape):
+    """K % 64 != 0, K % 8 == 0.  The classic geometries zero-fill the partial last K-step through out-of-range DMA lanes;
+    families q (16x16x32 members) and r run their "ktail" kernel variants (round 4): whole stages through the pipeline, the
+    remainder from fragments loaded straight from global memory (they need one whole stage: a geometry whose stage is deeper
+    than K is served by the any-shape kernel, also exact).  Every geometry x split-K form (+ family r's load flags), plus the
+    library's own plan, bit-exact; guard: NaN-prefilled C."""
     m, n, k = shape
+    L = g.lib()
     rng = np.random.default_rng(m + 3 * n + 5 * k)
     a, b = oracle.zero_one_inputs(m, n, k, rng)
     truth = oracle.truth_numpy(a, b)
     for entry in ("fp32", "fp16"):
         assert np.array_equal(g.gemm(a, b, entry).view(np.uint16), truth.view(np.uint16)), entry
     for cid, name in enumerate(g.config_names()):
-        if not name.startswith("t"):
+        if name[0] not in "tqr":
             continue
-        for splits in (1, 3, 2 | 0x10000):
+        for splits in (1, 3, 2 | 0x10000) + ((2 | 0x10000 | 0x180000,) if name[0] == "r" else ()):
             got = g.gemm(a, b, plan=(cid, splits, 2))
-            assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, splits)
+            assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (name, hex(splits))
+    q = g.config_names().index("q256x256_w2x2")
+    assert L.hgemm_mi355x_config_accepts_k(q, k) == (1 if k >= 64 else 0)   # (so the loop above ran its ktail variant, not a fallback)
     # operands that end exactly at the end of their allocation: the partial step must not read past it harmfully
     a_t = torch.from_numpy(a).cuda().clone()
     assert np.array_equal(g.gemm(a_t.cpu().numpy(), b).view(np.uint16), truth.view(np.uint16))
@@ -756,6 +766,15 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         ("w16x16_k4", 8 | 0x10000, (64, 64, 4096)),               # four waves per tile walk K, single-launch split-K on top
         ("w32x32_k4", 2 | 0x10000, (100, 260, 2112)),             # ... ragged edges, 33 slices per split over four waves
         ("w16x32_k4", 1, (48, 96, 1024)),                         # ... M = 48: one and a half tiles
+        # "ktail" kernel variants of families q and r (round 4): whole stages through the pipeline + fragments loaded directly
+        ("q256x256_w2x2", 1, (4608, 4608, 616)),                  # several items per workgroup: the tail runs at item seams (9 K-steps + 40)
+        ("q128x128_w2x2_k128", 1, (2304, 2304, 696)),             # ... BK = 128 stages, 5 stages + 56
+        ("q192x256_w2x2", 2 | 0x10000, (1000, 520, 4440)),        # single-launch split-K (the tail rides on the last split), ragged edges
+        ("q256x128_w2x2", 1, (4352, 4352, 1048)),                 # hybrid tail pass + K tail
+        ("q128x256_w2x2", 3, (1024, 1024, 4104)),                 # two-pass split-K, K % 64 = 8 (one quarter of a slice)
+        ("r64x64_k256", 1, (2048, 64, 9160)),                     # 35 stages + 200 (seven slices: trips of four, then singles)
+        ("r128x64_k128_d", 2 | 0x10000 | 0x100000, (4100, 64, 4168)),   # two LDS buffers, ragged M edge, fused split-K, NT loads
+        ("r64x128_k128", 4 | 0x80000, (192, 4000, 2104)),         # ragged N edge, two-pass split-K, per-XCD stagger
     ]
     for cfg, splits, (m, n, k) in cases:
         cid = names.index(cfg)

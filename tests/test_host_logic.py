@@ -99,8 +99,20 @@ def test_planner_routes_ragged_shapes_to_the_register_staged_mfma_kernel(lib):
     assert lib.hgemm_mi355x_plan(1000, 520, 200, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert cfg.value >= 0 and lib.hgemm_mi355x_config_name(cfg.value).decode().startswith("t")
     assert lib.hgemm_mi355x_config_k_granularity(cfg.value) == 8
+    # ... round 4: or a member of family q / r, whose "ktail" kernel variants accumulate the remainder from directly loaded fragments
     assert lib.hgemm_mi355x_plan(4000, 4000, 4000, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
-    assert cfg.value >= 0 and lib.hgemm_mi355x_config_name(cfg.value).decode().startswith("t")
+    assert cfg.value >= 0 and lib.hgemm_mi355x_config_name(cfg.value).decode() == "q256x256_w2x2"
+    assert lib.hgemm_mi355x_config_k_granularity(cfg.value) == 8 and lib.hgemm_mi355x_config_accepts_k(cfg.value, 4000) == 1
+    # (at least one whole stage must exist: K = 40 is not for them, and the 32x32x16 members have no tail)
+    assert lib.hgemm_mi355x_config_accepts_k(cfg.value, 40) == 0 and lib.hgemm_mi355x_config_accepts_k(cfg.value, 64) == 1
+    assert lib.hgemm_mi355x_config_accepts_k(cfg.value, 4004) == 0
+    m32 = lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2_m32")
+    assert m32 >= 0 and lib.hgemm_mi355x_config_accepts_k(m32, 4000) == 0 and lib.hgemm_mi355x_config_accepts_k(m32, 4032) == 1
+    r256 = lib.hgemm_mi355x_config_by_name(b"r64x64_k256")
+    assert [lib.hgemm_mi355x_config_accepts_k(r256, k) for k in (200, 256, 264, 512, 9160, 9164)] == [0, 1, 1, 1, 1, 0]
+    t = lib.hgemm_mi355x_config_by_name(b"t64x64_w2x2_m16_s4")
+    assert [lib.hgemm_mi355x_config_accepts_k(t, k) for k in (8, 40, 64, 200, 204)] == [1, 1, 1, 1, 0]
+    assert lib.hgemm_mi355x_config_accepts_k(-2, 7) == 1
     assert lib.hgemm_mi355x_plan(1000, 520, 192, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == 0
     assert cfg.value >= 0                              # aligned: an LDS-DMA geometry
     assert lib.hgemm_mi355x_plan(0, 4, 4, ctypes.byref(cfg), ctypes.byref(splits), ctypes.byref(group)) == -1
@@ -454,9 +466,13 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
         t = threading.Thread(target=lambda: other.append(plan(m, n, k)))
         t.start(); t.join()
         assert other == [(cfg, splits, group)]
-    # K % 64 != 0: the persistent families' plans do not fit, whatever is chosen must accept the K tail
-    cfg, splits, _ = plan(4000, 4000, 4000)
-    assert lib.hgemm_mi355x_config_k_granularity(cfg) == 8 and lib.hgemm_mi355x_config_name(cfg).decode().startswith("t")
+    # K % 64 != 0: whatever is chosen must accept the K tail (round 4: the corner plans of families q and r do)
+    for (m, n, k) in [(4000, 4000, 4000), (1332, 3108, 4440), (64, 16384, 9160), (12032, 2048, 7152), (1000, 520, 200), (72, 4096, 72)]:
+        cfg, splits, _ = plan(m, n, k)
+        assert lib.hgemm_mi355x_config_k_granularity(cfg) == 8 and lib.hgemm_mi355x_config_accepts_k(cfg, k) == 1, (m, n, k)
+        assert not (splits & 0x40000) or lib.hgemm_mi355x_config_name(cfg).decode()[0] == "t"   # no stream-K kernel with a direct tail
+    assert lib.hgemm_mi355x_config_name(plan(4000, 4000, 4000)[0]).decode() == "q256x256_w2x2"
+    assert lib.hgemm_mi355x_config_name(plan(64, 16384, 9160)[0]).decode()[0] == "r"
     # 33 distinct off-grid shapes map onto 32 memo slots: evictions must not change any answer
     shapes = [(1000 + 8 * i, 520, 704) for i in range(33)]
     first = [plan(*s) for s in shapes]
@@ -485,6 +501,9 @@ def test_planner_fuzz_every_answer_is_launchable(lib):
         assert 0 <= c.value < n_cfg, (m, n, k, c.value)
         gran = lib.hgemm_mi355x_config_k_granularity(c.value)
         assert k % gran == 0, (m, n, k, lib.hgemm_mi355x_config_name(c.value), gran)
+        assert lib.hgemm_mi355x_config_accepts_k(c.value, k) == 1, (m, n, k, lib.hgemm_mi355x_config_name(c.value))
+        name = lib.hgemm_mi355x_config_name(c.value).decode()
+        assert not (s.value & 0x40000) or k % 64 == 0 or name[0] == "t", (m, n, k, name)   # stream-K + K tail: classic family only
         assert (s.value & ~0x1FFFFF) == 0 and g.value >= 1
         assert not (s.value & 0x180000) or lib.hgemm_mi355x_config_name(c.value).decode()[0] == "r"   # family r's load flags: r plans only
         assert ((s.value & 0x40000) and lib.hgemm_mi355x_config_streamk(c.value) > 0 and (s.value & 0xFFFF) <= 4096) or \

@@ -51,6 +51,33 @@ def test_tile_matches_numpy_and_is_bank_conflict_free(geo):
                 assert out[(m, n)] == ref[m, n], (m, n)
 
 
+@pytest.mark.parametrize("geo", [(64, 64, 2, 2, 16), (128, 64, 2, 2, 16), (32, 64, 1, 2, 16)])
+@pytest.mark.parametrize("k", [64 + 8, 128 + 24, 64 + 32, 128 + 56, 256 + 200])
+def test_whole_stages_plus_direct_k_tail_match_numpy(geo, k):
+    """The "ktail" kernel variants of families q and r (round 4): the whole stages of K through the pipeline, the remaining
+    k % stage elements (a multiple of 8) from fragments loaded straight from the operands, lanes past K and rows past the edge
+    reading zeros through the descriptor range.  Every C element of ragged edge tiles equals numpy's; the model also asserts
+    that no real (unmasked) offset leaves its operand (the last row of the last tile ends with the allocation)."""
+    rng = np.random.default_rng(k)
+    g = klm.Geometry(*geo)
+    M, N = g.BM + 8, g.BN + 12
+    A = rng.integers(-3, 4, size=(M, k)).astype(np.float32)
+    Bt = rng.integers(-3, 4, size=(N, k)).astype(np.float32)
+    ref = A @ Bt.T
+    for stage in (64, 128, 256):
+        k_whole = k // stage * stage
+        if k_whole == 0 or k_whole == k:
+            continue
+        for (m0, n0) in [(0, 0), (g.BM, g.BN), (g.BM, 0)]:
+            tail = klm.direct_k_tail(g, A, Bt, m0, n0, k_whole, k)
+            out, _ = klm.run_tile(g, A, Bt, m0, n0, oob_zero=True, k_whole=k_whole, extra_acc=tail)
+            rows, cols = range(m0, min(M, m0 + g.BM)), range(n0, min(N, n0 + g.BN))
+            assert len(out) == len(rows) * len(cols)
+            for m in rows:
+                for n in cols:
+                    assert out[(m, n)] == ref[m, n], (stage, m0, n0, m, n)
+
+
 def test_linear_lds_would_conflict():
     """Sanity of the conflict model itself: without the XOR the same reads are 4-way conflicted."""
     g = klm.Geometry(64, 64, 2, 2, 16)
