@@ -228,7 +228,17 @@ double model_us(const KernelEntry& e, int M, int N, int K, int splits) {
   const double step_tp = conc * (2.0 * e.bm * e.bn * BK) / (kCuFlopUs * eff);
   // per-K-step latency floor: barrier + LDS-DMA round trip (double-buffered rings expose all of it)
   const double step_lat = family == 's' ? 0.40 : (e.nbuf >= 3 ? 0.33 : 0.74);
-  const double main_us = rounds * (1.0 + ksteps * std::max(step_tp, step_lat));
+  double main_us = rounds * (1.0 + ksteps * std::max(step_tp, step_lat));
+  // Rows that are not a multiple of 128 bytes apart (K % 64 != 0: only shapes off the grid): every 128-byte row segment of an
+  // LDS-DMA piece straddles two cache lines, and the kernels that are bound by piece issue rather than by MFMA time pay for it in
+  // proportion to their pieces per MFMA cycle, x = 4 (BM + BN) / (BM BN).  Round 4, first measurements of families q with a K tail
+  // (tuning/r04_ktail_candidates_mi355x.jsonl, K = 4440 / 7152 / 520): 128 x 256 tiles 1.40 us per K-step against 0.85 on the
+  // grid (+65 %, x = 0.047), 256 x 192 +24 % (x = 0.037), 256 x 256 +7 % (x = 0.031); capped where latency, not issue, bounds the
+  // small tiles.  Family r streams 256-512 contiguous bytes per row and is not charged.
+  if ((2 * K) % 128 != 0 && e.name[0] != 'r') {
+    const double x = 4.0 * (e.bm + e.bn) / ((double)e.bm * e.bn);
+    main_us *= 1.0 + std::min(0.5, std::max(0.0, 25.0 * x - 0.675));
+  }
   double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
   double extra = 0.0;
   if (splits > 1) {
@@ -355,7 +365,11 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       *cfg = p->cfg;
       *splits = s > 1 ? (s | (p->splits & HGEMM_SPLITK_FUSED)) : 1;
       // family r's load flags travel with the corner plan (they belong to the access pattern of the shape class, not to the shape)
-      if (e.name[0] == 'r') *splits |= p->splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS);
+      // -- while the rows stay a multiple of 4 KiB apart, as on the grid: the flags answer workgroups that walk the same K offset
+      // of such rows hitting the same few channels and evicting the shared operand.  With any other stride there is nothing to
+      // answer (64 x 16384 x 9160, stride 18320 B: r64x128_k128 split 2 63.8 us plain, 70.3 with both flags; r64x64_k256 66.3 /
+      // 69.8; 128 x 8192 x 9616: 52.4 / 53.8 -- tuning/r04_ktail_candidates_mi355x.jsonl)
+      if (e.name[0] == 'r' && (2 * K) % 4096 == 0) *splits |= p->splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS);
       *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
     }
   }
@@ -382,6 +396,42 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
           *cfg = c;
           *splits = s > 1 ? (s | best_fused) : 1;
           *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
+        }
+      }
+    }
+  }
+  // A corner plan of family q was tuned on a shape whose tiles fill the resident workgroups; off the grid the same tile may leave
+  // much of the last (or only) round empty (1332 x 3108 x 4440: 143 tiles of 128 x 256 on 256 workgroups = 84.7 us, where 204 items
+  // of 256 x 192 at two splits take 60.0 and 156 of 256 x 256 at two splits 66.0 -- tuning/r04_ktail_candidates_mi355x.jsonl).
+  // When the chosen q plan is a single round that fills less than 80 % of the resident workgroups, its siblings join the ranking
+  // at one, two and four splits -- inside the family the model prices on one scale -- provided they do not fill their rounds worse.  (More
+  // than one round is the hybrid tail schedule's case, hgemm_mi355x_launch; the 192-wide members keep their own, measured rule
+  // above.)
+  if (found && !(*splits & HGEMM_PLAN_STREAMK) && g_kernel_table[*cfg].name[0] == 'q' && g_kernel_table[*cfg].mi == 16) {
+    auto fill_of = [&](const KernelEntry& e, int s) {
+      const long items = (long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) * s, cap = std::max(1, e.persistent_wgs);
+      return (double)items / (double)(((items + cap - 1) / cap) * cap);
+    };
+    const KernelEntry& e0 = g_kernel_table[*cfg];
+    const int s0 = std::max(1, *splits & HGEMM_SPLITK_MASK);
+    const double fill0 = fill_of(e0, s0);
+    if (fill0 < 0.8 && (long)((M + e0.bm - 1) / e0.bm) * ((N + e0.bn - 1) / e0.bn) * s0 <= e0.persistent_wgs) {
+      const int fused0 = *splits & HGEMM_SPLITK_FUSED;
+      for (const char* name : {"q256x256_w2x2", "q256x128_w2x2", "q128x256_w2x2", "q128x128_w2x2_k128"}) {
+        const int c = hgemm_mi355x_config_by_name(name);
+        if (c < 0) continue;
+        const KernelEntry& e = g_kernel_table[c];
+        if (!k_ok(e, K) || (e.bm > M * 2 && e.bm > 32) || (e.bn > N * 2 && e.bn > 32)) continue;
+        for (int s : {1, 2, 4}) {
+          if (s > 1 && K / s < 1024) break;
+          if (fill_of(e, s) < fill0) continue;
+          const double t = model_us(e, M, N, K, s);
+          if (t < best) {
+            best = t;
+            *cfg = c;
+            *splits = s > 1 ? (s | fused0) : 1;
+            *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
+          }
         }
       }
     }

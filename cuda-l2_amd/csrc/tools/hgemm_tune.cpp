@@ -317,7 +317,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     HIP_OK(hipMemcpy(s.bt, z.bt.data(), z.bt.size() * 2, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(s.b, b_rm.data(), b_rm.size() * 2, hipMemcpyHostToDevice));
     for (int c = HGEMM_CONFIG_RAGGED; c < nc; ++c) {
-      if (c >= 0 && sh.K % 64 == 0 && sh.K % hgemm_mi355x_config_k_granularity(c) != 0) continue;  // BK=128 member, K = 64 (mod 128)
+      if (c >= 0 && sh.K % 64 == 0 && !hgemm_mi355x_config_accepts_k(c, sh.K)) continue;  // BK=128 member, K = 64 (mod 128): the launch refuses
       const char* cname = c >= 0 ? hgemm_mi355x_config_name(c) : (c == HGEMM_CONFIG_GENERIC ? "generic" : "ragged");
       if (!g_config_filter.empty() && std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) == g_config_filter.end())
         continue;   // --configs: only these (the special ids are "generic" / "ragged")

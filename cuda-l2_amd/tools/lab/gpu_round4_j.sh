@@ -17,7 +17,7 @@ if [ $rc -ne 0 ]; then grep -m 40 FAIL $O/check_final.log; echo "STOP: check fai
 QS=q256x256_w2x2,q256x128_w2x2,q128x256_w2x2,q128x128_w2x2_k128,q128x128_w2x2,q192x256_w2x2,q256x192_w2x2
 timeout 300 $T check --shapes 4352_4352_328,4608_4352_200,3000_4400_456 --configs $QS > $O/check_q_item_seams.log 2>&1; rc=$?; echo "seam check rc=$rc"; tail -1 $O/check_q_item_seams.log
 if [ $rc -ne 0 ]; then grep -m 40 FAIL $O/check_q_item_seams.log; echo "STOP: seam check failed"; exit 1; fi
-HGEMM_RECORD_DIR=$O/records timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8
+HGEMM_RECORD_DIR=$O/records timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tee $O/pytest_gpu.log | tail -8; grep -E "^(FAILED|E  +Assert)" $O/pytest_gpu.log | head -20
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 200 $T tune --plan-only --baselines --stream --shape-file cuda-l2_amd/tools/offgrid_shapes.txt --out $O/offgrid_plan_report.jsonl > $O/offgrid_plan_report.log 2>&1; echo "offgrid report lines=$(wc -l < $O/offgrid_plan_report.jsonl)"
 timeout 240 $T tune --shape-file cuda-l2_amd/tuning/r04_ktail_shapes.txt --cand-file cuda-l2_amd/tuning/r04_ktail_candidates.txt --rank both --baselines --stream --out $O/ktail_candidates.jsonl > $O/ktail_candidates.log 2>&1; echo "ktail tune rc=$? lines=$(wc -l < $O/ktail_candidates.jsonl)"

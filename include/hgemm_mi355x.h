@@ -87,6 +87,8 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * HGEMM_PLAN_RS_XCD_STAGGER: the K stagger of the family (workgroups start their K walk at different stages so that the chip does
  *   not read one K offset of rows 16-32 KiB apart at the same time) is taken per XCD instead of per tile: the workgroups of an
  *   XCD walk K in lock-step and share the slices of the small operand in that XCD's L2; the eight XCDs are nk / 8 stages apart.
+ *   (The summation order of a tile then depends on which workgroup computes it: "per plan" includes the raster group, as it does
+ *   for a stream-K plan.)
  * HGEMM_PLAN_RS_NT_LOADS: the STREAMED operand (the one with more rows, read exactly once) is loaded non-temporally, so it does
  *   not push the shared operand's slices out of the L2 (what hipBLASLt's kernels do on the skinny shapes: NTA / NTB). */
 #define HGEMM_PLAN_RS_XCD_STAGGER 0x80000

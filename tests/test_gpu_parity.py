@@ -786,8 +786,9 @@ def test_race_screen_repeated_runs_are_bit_identical(g):
         for rep in range(50):
             c.fill_(float("nan"))
             # (a stream-K run cuts the tiles where the raster order puts them: the summation grouping is a function of the
-            # plan, raster group included, so those paths keep one group)
-            group = 4 if splits & 0x40000 else int(rng.choice([1, 2, 3, 4, 8, 16]))
+            # plan, raster group included, so those paths keep one group; the same holds for family r's per-XCD stagger, whose
+            # K walk starts where the workgroup's XCD says: the raster group decides which workgroup gets the tile)
+            group = 4 if splits & (0x40000 | 0x80000) else int(rng.choice([1, 2, 3, 4, 8, 16]))
             assert L.hgemm_mi355x_launch(cid, splits, group, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c.data_ptr(), m, n, k, k, k, n,
                                          g.stream()) == 0
             torch.cuda.synchronize()

@@ -482,6 +482,36 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
     assert plan(3072, 3072, 3072)[0] == lib.hgemm_mi355x_config_by_name(b"q192x256_w2x2")
 
 
+def test_off_grid_rules_of_round_4(lib):
+    """Three rules the first K-tail measurements of families q and r suggested (tuning/r04_ktail_candidates_mi355x.jsonl, DESIGN.md
+    section 4.13): (1) family r's load flags travel with a corner plan only while the rows stay a multiple of 4 KiB apart; (2) a
+    single, under-filled round of a q corner plan lets the family's siblings in at one / two / four splits; (3) the model charges
+    the LDS-DMA families for rows that are not 128-byte aligned, in proportion to their pieces per MFMA cycle."""
+    lib.hgemm_mi355x_model_us.restype = ctypes.c_double
+
+    def plan(m, n, k):
+        c, s, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.hgemm_mi355x_plan(m, n, k, ctypes.byref(c), ctypes.byref(s), ctypes.byref(g)) == 0
+        return lib.hgemm_mi355x_config_name(c.value).decode(), s.value
+
+    # (1) stride 20480 B = 5 x 4 KiB: flags kept; 18320 B / 18432 B: dropped (the geometry and the split form stay)
+    assert plan(64, 16384, 10240) == ("r64x128_k128_d", 0x110002)
+    assert plan(64, 16384, 9160) == ("r64x128_k128_d", 0x10002) and plan(64, 16384, 9216) == ("r64x128_k128_d", 0x10002)
+    for (m, n, k) in [(16000, 128, 16000), (128, 8192, 9616), (64, 14928, 10624), (100, 16384, 16384), (64, 12000, 16384)]:
+        name, s = plan(m, n, k)
+        assert name[0] == "r" and bool(s & 0x180000) == ((2 * k) % 4096 == 0), (m, n, k, name, hex(s))
+    # (2) 143 tiles of 128 x 256 on 256 workgroups (the corner plan of 2048 x 4096 x 4096) -> 156 items of 256 x 256 at two splits
+    assert plan(1332, 3108, 4440) == ("q256x256_w2x2", 2)
+    assert plan(2048, 4096, 4096)[0] == "q128x256_w2x2"                      # the corner itself: a tuned row, untouched
+    assert plan(4352, 4352, 4096) == ("q256x256_w2x2", 1)                    # more than one round: the hybrid tail's case, not this rule's
+    # (3) K = 4440 against K = 4416 (69 whole steps): 128 x 256 tiles +50 %, 256 x 256 tiles +10.6 %, family r not charged
+    q128, q256, r = (lib.hgemm_mi355x_config_by_name(x) for x in (b"q128x256_w2x2", b"q256x256_w2x2", b"r64x128_k128"))
+    def ratio(c, m, n, k0, k1):
+        return lib.hgemm_mi355x_model_us(c, 1, m, n, k1) / lib.hgemm_mi355x_model_us(c, 1, m, n, k0)
+    assert 1.45 < ratio(q128, 1332, 3108, 4416, 4440) < 1.55 and 1.09 < ratio(q256, 1332, 3108, 4416, 4440) < 1.14
+    assert ratio(r, 64, 16384, 9216, 9160) == 1.0 and ratio(q128, 1332, 3108, 4416, 4480) < 1.03
+
+
 def test_planner_fuzz_every_answer_is_launchable(lib):
     """Random shapes (aligned and not): the planner always answers with a geometry whose K granularity divides K (or
     a special id), a split count a launch would accept, and a raster group >= 1."""
