@@ -365,11 +365,13 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       *cfg = p->cfg;
       *splits = s > 1 ? (s | (p->splits & HGEMM_SPLITK_FUSED)) : 1;
       // family r's load flags travel with the corner plan (they belong to the access pattern of the shape class, not to the shape)
-      // -- while the rows stay a multiple of 4 KiB apart, as on the grid: the flags answer workgroups that walk the same K offset
-      // of such rows hitting the same few channels and evicting the shared operand.  With any other stride there is nothing to
-      // answer (64 x 16384 x 9160, stride 18320 B: r64x128_k128 split 2 63.8 us plain, 70.3 with both flags; r64x64_k256 66.3 /
-      // 69.8; 128 x 8192 x 9616: 52.4 / 53.8 -- tuning/r04_ktail_candidates_mi355x.jsonl)
-      if (e.name[0] == 'r' && (2 * K) % 4096 == 0) *splits |= p->splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS);
+      // -- while the rows stay 128-byte aligned (K % 64 == 0).  With rows that straddle cache lines a non-temporal load drops the
+      // half line the next K stage of the same row needs again, and the flags cost instead of paying: 64 x 16384 x 9160 (stride
+      // 18320 B) r64x128_k128 split 2 64.0 us plain / 70.6 with both flags, r64x64_k256 66.8 / 70.3, the corner plan itself
+      // (r64x128_k128_d, NT loads) 73.6 -> 67.7 without; with aligned rows off the grid they keep paying (16000 x 128 x 16000
+      // 0.81 -> 0.79 of hipBLASLt without them, 128 x 16000 x 16000 0.99 -> 0.95, 64 x 14928 x 10624 0.77 -> 0.73:
+      // tuning/r04_ktail_candidates_mi355x.jsonl, r04_offgrid_plan_report_call_j3_no_r_flags_mi355x.jsonl)
+      if (e.name[0] == 'r' && K % 64 == 0) *splits |= p->splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS);
       *group_m = default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn);
     }
   }

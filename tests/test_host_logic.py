@@ -484,7 +484,7 @@ def test_off_grid_shapes_are_planned_from_the_surrounding_grid_plans(lib):
 
 def test_off_grid_rules_of_round_4(lib):
     """Three rules the first K-tail measurements of families q and r suggested (tuning/r04_ktail_candidates_mi355x.jsonl, DESIGN.md
-    section 4.13): (1) family r's load flags travel with a corner plan only while the rows stay a multiple of 4 KiB apart; (2) a
+    section 4.13): (1) family r's load flags travel with a corner plan only while the rows stay 128-byte aligned (K % 64 == 0); (2) a
     single, under-filled round of a q corner plan lets the family's siblings in at one / two / four splits; (3) the model charges
     the LDS-DMA families for rows that are not 128-byte aligned, in proportion to their pieces per MFMA cycle."""
     lib.hgemm_mi355x_model_us.restype = ctypes.c_double
@@ -494,12 +494,11 @@ def test_off_grid_rules_of_round_4(lib):
         assert lib.hgemm_mi355x_plan(m, n, k, ctypes.byref(c), ctypes.byref(s), ctypes.byref(g)) == 0
         return lib.hgemm_mi355x_config_name(c.value).decode(), s.value
 
-    # (1) stride 20480 B = 5 x 4 KiB: flags kept; 18320 B / 18432 B: dropped (the geometry and the split form stay)
-    assert plan(64, 16384, 10240) == ("r64x128_k128_d", 0x110002)
-    assert plan(64, 16384, 9160) == ("r64x128_k128_d", 0x10002) and plan(64, 16384, 9216) == ("r64x128_k128_d", 0x10002)
-    for (m, n, k) in [(16000, 128, 16000), (128, 8192, 9616), (64, 14928, 10624), (100, 16384, 16384), (64, 12000, 16384)]:
+    # (1) rows of 18432 B (K = 9216) keep the corner plan's flags, rows of 18320 B (K = 9160) drop them (geometry and split form stay)
+    assert plan(64, 16384, 9216) == ("r64x128_k128_d", 0x110002) and plan(64, 16384, 9160) == ("r64x128_k128_d", 0x10002)
+    for (m, n, k) in [(16000, 128, 16000), (128, 8192, 9616), (64, 14928, 10624), (100, 16384, 16384), (64, 12000, 16384), (128, 16000, 16000)]:
         name, s = plan(m, n, k)
-        assert name[0] == "r" and bool(s & 0x180000) == ((2 * k) % 4096 == 0), (m, n, k, name, hex(s))
+        assert name[0] == "r" and bool(s & 0x180000) == (k % 64 == 0), (m, n, k, name, hex(s))
     # (2) 143 tiles of 128 x 256 on 256 workgroups (the corner plan of 2048 x 4096 x 4096) -> 156 items of 256 x 256 at two splits
     assert plan(1332, 3108, 4440) == ("q256x256_w2x2", 2)
     assert plan(2048, 4096, 4096)[0] == "q128x256_w2x2"                      # the corner itself: a tuned row, untouched
