@@ -166,6 +166,37 @@ def test_late_candidate_generator_starts_every_line_with_the_shipped_plan(capsys
             assert L.hgemm_mi355x_config_by_name(name.encode()) >= 0 and int(s) & 0xFFFF >= 1 and int(g) >= 1
 
 
+def test_k_tail_figures_match_the_records():
+    """the before / after figures of the off-grid shapes with a K tail come from the two committed off-grid
+    reports (closing run G = before the ktail variants of families q and r, call K = the final library), the kernel names and
+    roofline fractions from the PMC table of call K, the run counts from the committed check logs."""
+    d = _design()
+    before = {r["mnk"]: r for r in _recs(PKG / "tuning" / "r04_offgrid_plan_report_before_ktail_mi355x.jsonl")}
+    after = {r["mnk"]: r for r in _recs(PKG / "tuning" / "r04_offgrid_plan_report_mi355x.jsonl")}
+    kt = [k for k in after if int(k.split("_")[2]) % 64 and int(k.split("_")[2]) % 8 == 0]
+    assert len(kt) == 14 and set(before) == set(after)
+    iso = lambda r: min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"]
+    b2b = lambda r: min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) / r["stream_us"]
+    for recs, f in ((before, iso), (after, iso), (before, b2b), (after, b2b)):
+        assert f"{_gm(f(recs[k]) for k in kt):.3f}" in d
+    assert f"{_gm(b2b(r) for r in after.values()):.3f}" in d and f"{_gm(b2b(r) for r in before.values()):.3f}" in d
+    # every K-tail shape that left the classic family runs a ktail variant of family q or r now, and none of them got slower against hipBLASLt by more than noise
+    moved = [k for k in kt if after[k]["best"]["config"] != before[k]["best"]["config"]]
+    assert len(moved) == 11 and all(after[k]["best"]["config"][0] in "qr" and before[k]["best"]["config"][0] == "t" for k in moved)
+    assert all(iso(after[k]) > iso(before[k]) - 0.02 for k in moved)
+    for k, want in (("1332_3108_4440", "0.93"), ("12032_2048_7152", "0.91"), ("64_16384_9160", "0.95")):
+        assert f"{iso(after[k]):.2f}" == want and want in d
+    tab = json.loads((REPO / "profiles" / "r04_pmc_ktail_table.json").read_text())["rows"]
+    assert len(tab) == 6
+    for row in tab:   # the kernel that ran carries EPI_KTAIL (epilogue id 8..11) in its template arguments
+        assert re.search(r"hgemm_tn_(sq|rs)_kernel<Cfg\w+<[\d, ]+>, (8|9|10|11)>", row["kernels"][0]), row["kernels"]
+    r4000 = next(r for r in tab if r["mnk"] == "4000_4000_4000")
+    assert f"{r4000['roofline']['frac']:.3f}" in d and f"{r4000['tflops']:.0f} TFLOP/s" in d
+    seams = (REPO / "profiles" / "r04_check_q_item_seams.log").read_text()
+    m = re.search(r"check: (\d+) runs, 0 failures", seams)
+    assert m and f"{m.group(1)} runs" in d
+
+
 def test_tuner_results_were_checked_before_they_were_timed():
     """Process rule of round 4 (tools/lab/README.md; VERDICT r3: a knob had been A/B-timed on 436 plans before it was ever run through
     `hgemm_tune check`, and computed wrong results): every round-4 tuner result file under cuda-l2_amd/tuning/ is listed in
