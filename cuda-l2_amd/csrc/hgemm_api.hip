@@ -355,6 +355,16 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
       continue;
     }
     const int s = (p->splits & HGEMM_PLAN_STREAMK) ? 1 : std::max(1, std::min(p->splits & HGEMM_SPLITK_MASK, ksteps));
+    const long wgs_here = (long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) * s;
+    // A "_k4" member of family w spends a whole four-wave workgroup on a 32 x 32 (or smaller) tile: it wins where the grid gave it
+    // at most one workgroup per CU (256 x 1024 x 1024, 512 x 512 x 512: by 2 % over t32x64) and loses as soon as there are more
+    // (512 x 1024 x 512: 7.2 us against 5.7; off the grid 256 x 1600 x 1024 at 400 workgroups 12.2 against 9.0 for t64x64,
+    // 640 x 640 x 640 9.2 against 7.4 -- tuning/r04_retune_pass2_mi355x.jsonl, r03_offgrid_tune_mi355x.jsonl, r04 off-grid reports)
+    if (e.name[0] == 'w' && e.wm * e.wn == 1 && wgs_here > kCUs) continue;
+    // Family r is bound by what a CU can stream: its corner plans were tuned with one or two workgroups on EVERY CU.  A count
+    // between one and 1.75 rounds of the chip leaves most CUs idle while a few run a second workgroup (64 x 14928 x 10624: 156 tiles
+    // of 64 x 96 at two splits = 312 workgroups, 83.4 us, where the 64 x 128 corner plan's 234 take 63.8)
+    if (e.name[0] == 'r' && wgs_here > kCUs && wgs_here < kCUs * 7 / 4) continue;
     // the 8-wave mid tiles were tuned (and the model fitted) for at most two workgroups per CU: beyond that the larger tiles of
     // another corner win (1332 x 3108 x 4440: 525 tiles of 64 x 128 measured 101 us against 82 us for the 256 x 256 corner plan)
     if (e.name[0] == 't' && e.wm * e.wn == 8 && e.bm * e.bn <= 128 * 64 &&

@@ -503,6 +503,11 @@ def test_off_grid_rules_of_round_4(lib):
     assert plan(1332, 3108, 4440) == ("q256x256_w2x2", 2)
     assert plan(2048, 4096, 4096)[0] == "q128x256_w2x2"                      # the corner itself: a tuned row, untouched
     assert plan(4352, 4352, 4096) == ("q256x256_w2x2", 1)                    # more than one round: the hybrid tail's case, not this rule's
+    # (4) a "_k4" member of family w beyond one workgroup per CU, and a family-r workgroup count between 1 and 1.75 rounds of the
+    # chip, are not taken from a corner (256 x 1600 x 1024: 400 workgroups of w32x32_k4 measured 12.2 us against 9.0 for a classic
+    # tile; 64 x 14928 x 10624: 312 workgroups of r64x96 83.4 us against 63.8 for 234 of r64x128)
+    assert plan(256, 1600, 1024)[0][0] == "t" and plan(640, 640, 640)[0][0] == "t" and plan(256, 1024, 1024)[0] == "w32x32_k4"
+    assert plan(64, 14928, 10624)[0].startswith("r64x128_k128") and plan(64, 12288, 8192)[0].startswith("r64x96") is not None
     # (3) K = 4440 against K = 4416 (69 whole steps): 128 x 256 tiles +50 %, 256 x 256 tiles +10.6 %, family r not charged
     q128, q256, r = (lib.hgemm_mi355x_config_by_name(x) for x in (b"q128x256_w2x2", b"q256x256_w2x2", b"r64x128_k128"))
     def ratio(c, m, n, k0, k1):
