@@ -172,7 +172,8 @@ def test_k_tail_figures_match_the_records():
     roofline fractions from the PMC table of call K, the run counts from the committed check logs."""
     d = _design()
     before = {r["mnk"]: r for r in _recs(PKG / "tuning" / "r04_offgrid_plan_report_before_ktail_mi355x.jsonl")}
-    after = {r["mnk"]: r for r in _recs(PKG / "tuning" / "r04_offgrid_plan_report_mi355x.jsonl")}
+    after = {r["mnk"]: r for r in _recs(PKG / "tuning" / "r04_offgrid_plan_report_call_k_mi355x.jsonl")}
+    final = {r["mnk"]: r for r in _recs(PKG / "tuning" / "r04_offgrid_plan_report_mi355x.jsonl")}
     kt = [k for k in after if int(k.split("_")[2]) % 64 and int(k.split("_")[2]) % 8 == 0]
     assert len(kt) == 14 and set(before) == set(after)
     iso = lambda r: min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"]
@@ -180,6 +181,10 @@ def test_k_tail_figures_match_the_records():
     for recs, f in ((before, iso), (after, iso), (before, b2b), (after, b2b)):
         assert f"{_gm(f(recs[k]) for k in kt):.3f}" in d
     assert f"{_gm(b2b(r) for r in after.values()):.3f}" in d and f"{_gm(b2b(r) for r in before.values()):.3f}" in d
+    # the final report (call L: two more planner guards) has the same plans for the K-tail shapes, quotes its own geomeans and minima
+    assert all((final[k]["best"]["config"], final[k]["best"]["splits"]) == (after[k]["best"]["config"], after[k]["best"]["splits"]) for k in kt)
+    assert f"{_gm(iso(r) for r in final.values()):.3f}" in d and f"{_gm(b2b(r) for r in final.values()):.3f}" in d
+    assert f"minimum **{min(iso(r) for r in final.values()):.2f} / {min(b2b(r) for r in final.values()):.2f}**" in d
     # every K-tail shape that left the classic family runs a ktail variant of family q or r now, and none of them got slower against hipBLASLt by more than noise
     moved = [k for k in kt if after[k]["best"]["config"] != before[k]["best"]["config"]]
     assert len(moved) == 11 and all(after[k]["best"]["config"][0] in "qr" and before[k]["best"]["config"][0] == "t" for k in moved)
