@@ -1,5 +1,6 @@
 // Any-shape MFMA kernel: C[M,N] = A[M,K] * B[K,N] for shapes the LDS-DMA families cannot take
-// (K % 64 != 0, N % 4 != 0, row strides or base pointers that are not 16-byte aligned).
+// (K % 8 != 0, N % 4 != 0, row strides or base pointers that are not 16-byte aligned; K % 64 != 0 with K % 8 == 0 has its own
+// paths since rounds 2 / 4: the classic family pads its last LDS-DMA step, families q and r run their ktail variants).
 //
 // The reference covers arbitrary sizes with harness-side zero padding to the tile size
 // (tools/utils.py:8-36, README.md:83-86: "pad to the nearest larger config"); here the padding happens

@@ -16,7 +16,9 @@
 //     8-lane groups of ds_write_b128 (8 consecutive chunks of one row) and the 16-lane groups of the fragment
 //     ds_read_b128 (16 rows, one chunk column); the XOR of the K slice folds into one v_xor per read;
 //   * MFMA loop, operand swap and epilogues (direct / split-K slabs / single-launch split-K) are hgemm_tn_kernel's.
-// Geometry: 4 waves (2 x 2), 16x16x32 MFMA.  K and every split-K chunk must be multiples of BKS.
+// Geometry: 4 waves (2 x 2), 16x16x32 MFMA.  Every split-K chunk is a multiple of BKS; so is K, or (round 4) the kernel's "ktail"
+// variant walks the whole stages and accumulates the remaining K % BKS (a multiple of 8) from fragments loaded straight from
+// global memory (hgemm_kernel.hpp: direct_k_tail).
 #pragma once
 
 #include "hgemm_kernel.hpp"

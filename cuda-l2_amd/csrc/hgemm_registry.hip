@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) hgemm_tail_reduce_kernel(const GemmArgs g
 }
 
 // Any-shape / any-alignment fallback (one output per thread, fp32 accumulate).  Correctness
-// net for shapes the MFMA path does not accept (K % 64 != 0, unaligned views); never tuned.
+// net for shapes the MFMA paths do not accept (K % 8 != 0, unaligned views); never tuned.
 __global__ void __launch_bounds__(256) hgemm_generic_kernel(const f16* __restrict__ A,
                                                             const f16* __restrict__ B,
                                                             f16* __restrict__ C, int M, int N, int K,
