@@ -601,18 +601,22 @@ __device__ __forceinline__ void stage_tile_tail(__amdgpu_buffer_rsrc_t rsA, __am
 // products are never stored), and a lane whose 8 halfs lie at k >= k_end gets bit 31 into its offset -- out of range as
 // well, so the last, partial slice is zero-filled per lane (the mark of stage_tile_tail).  U slices, U (FM + FN) loads,
 // are in flight behind one wait.  mfma(i, j, b, a) accumulates the fragment pair of A row block i and B row block j.
+// Buffer descriptor of an operand's rows from `base` on: `bytes` long, at most `cap`.  Base and range are made PROVABLY uniform
+// (readfirstlane), or hipcc wraps every buffer instruction that uses the descriptor in a waterfall loop.
+template <unsigned long long CAP>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const f16* base, size_t bytes) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
+  const uintptr_t uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
+  const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > CAP ? CAP : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, nrec, 0x00020000);
+}
+
 template <int FM, int FN, class F>
 __device__ __forceinline__ void direct_k_tail(const GemmArgs& g, int m0, int n0, int row_a, int row_b, int k0, int k_end, int lane,
                                               F&& mfma) {
-  auto rsrc_of = [](const f16* base, size_t bytes) {
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
-    const uintptr_t uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
-    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0x80000000ull ? 0x80000000ull : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, nrec, 0x00020000);
-  };
-  const __amdgpu_buffer_rsrc_t rsA = rsrc_of(g.A + (size_t)m0 * g.lda, ((size_t)(g.M - m0) * g.lda) * 2);
-  const __amdgpu_buffer_rsrc_t rsB = rsrc_of(g.Bt + (size_t)n0 * g.ldb, ((size_t)(g.N - n0) * g.ldb) * 2);
+  const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc<0x80000000ull>(g.A + (size_t)m0 * g.lda, ((size_t)(g.M - m0) * g.lda) * 2);
+  const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc<0x80000000ull>(g.Bt + (size_t)n0 * g.ldb, ((size_t)(g.N - n0) * g.ldb) * 2);
   const int l15 = lane & 15, lq = lane >> 4;
   uint32_t va[FM], vb[FN];   // byte offset of this lane's row of every 16-row block of the wave tile
 #pragma unroll

@@ -128,15 +128,8 @@ __device__ __forceinline__ void rs_mainloop(const GemmArgs& g, int m0, int n0, i
   // check always covers): rows past the edge are out of range and read as zeros (their products are never stored).
   constexpr int RP = THREADS / NCH;                       // tile rows between two chunks of a thread (8 or 16)
   const int r0 = tid / NCH, c0 = tid % NCH;
-  auto rsrc_of = [](const f16* base, size_t bytes) {
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
-    const uintptr_t uni = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
-    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, nrec, 0x00020000);
-  };
-  const __amdgpu_buffer_rsrc_t rsA = rsrc_of(g.A + (size_t)m0 * g.lda, ((size_t)(g.M - m0) * g.lda) * 2);
-  const __amdgpu_buffer_rsrc_t rsB = rsrc_of(g.Bt + (size_t)n0 * g.ldb, ((size_t)(g.N - n0) * g.ldb) * 2);
+  const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc<0xFFFFFFFFull>(g.A + (size_t)m0 * g.lda, ((size_t)(g.M - m0) * g.lda) * 2);
+  const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc<0xFFFFFFFFull>(g.Bt + (size_t)n0 * g.ldb, ((size_t)(g.N - n0) * g.ldb) * 2);
   const uint32_t voff_a = ((uint32_t)r0 * (uint32_t)g.lda + (uint32_t)c0 * 8u) * 2u;
   const uint32_t voff_b = ((uint32_t)r0 * (uint32_t)g.ldb + (uint32_t)c0 * 8u) * 2u;
   const uint32_t step_a = (uint32_t)RP * (uint32_t)g.lda * 2u, step_b = (uint32_t)RP * (uint32_t)g.ldb * 2u;

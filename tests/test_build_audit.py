@@ -476,3 +476,8 @@ def test_kernels_of_the_measured_library_keep_their_instruction_streams(isa_text
     # ... and the additions are what this change set out to add: ktail variants (epilogue id + 8) of families q and r
     added = sorted(set(now) - set(base))
     assert added and all(re.search(r"hgemm_tn_(sq|rs)_kernel.*ELi(8|9|10|11)EEEvNS", k) for k in added), added[:3]
+    # The library with those variants was checked and tested on the GPU in call K (profiles/r04_check_final.log, the -m gpu suite);
+    # source edits after it (comments, a shared descriptor helper) must leave EVERY kernel of it as it was: all 296, no exceptions.
+    call_k = json.loads((REPO / "profiles" / "r04_isa_fingerprint_call_k_library.json").read_text())["kernels"]
+    assert len(call_k) == 296 and set(call_k) == set(now)
+    assert not [k for k in call_k if now[k] != call_k[k]]
