@@ -202,6 +202,21 @@ def test_k_tail_figures_match_the_records():
     assert m and f"{m.group(1)} runs" in d
 
 
+def test_m32_counter_comparison_matches_its_record():
+    """the 32x32x16 member of family q takes the same GPU cycles as the 16x16x32 one and a lower clock."""
+    rec = json.loads((REPO / "profiles" / "r04_pmc_q256x256_m16_vs_m32_4096.json").read_text())
+    m16, m32 = rec["rows"]
+    assert (m16["config"], m32["config"]) == ("q256x256_w2x2", "q256x256_w2x2_m32") and "ELi32E" not in m16["kernel"]
+    d = _design()
+    assert f"{m32['gpu_cycles_per_xcd']:,}".replace(",", " ") in d and f"{m16['gpu_cycles_per_xcd']:,}".replace(",", " ") in d
+    assert abs(rec["reading"]["cycles_ratio_m32_over_m16"] - 1.0) < 0.02 and rec["reading"]["clock_ratio"] < 0.92
+    assert m16["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] == m32["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"]
+    for v in (m32["kernel_us"], m16["kernel_us"]):
+        assert f"{v:.1f} µs" in d
+    assert f"{m32['effective_clock_ghz']:.2f} GHz" in d and f"{m16['effective_clock_ghz']:.2f} GHz" in d
+    assert f"{m32['waves_parked_pct']} %" in d and f"{m16['waves_parked_pct']} %" in d
+
+
 def test_tuner_results_were_checked_before_they_were_timed():
     """Process rule of round 4 (tools/lab/README.md; VERDICT r3: a knob had been A/B-timed on 436 plans before it was ever run through
     `hgemm_tune check`, and computed wrong results): every round-4 tuner result file under cuda-l2_amd/tuning/ is listed in
