@@ -280,6 +280,21 @@ double model_us_streamk(const KernelEntry& e, int M, int N, int K, int G) {
 inline bool direct_tail(const KernelEntry& e) { return e.ktail && e.name[0] != 't'; }
 inline bool k_ok(const KernelEntry& e, int K) { return K % e.kgran == 0 || (e.ktail && K % 8 == 0 && (!direct_tail(e) || K >= e.kgran)); }
 
+// How a geometry cuts K for a split count the caller asked for: `steps` pipeline stages (rounded up for the classic family, whose
+// last step may be partial; rounded DOWN for a direct tail, which rides on the last split), at most one split per stage, no empty
+// split, chunks of whole stages.  Split s covers [s * k_chunk, min(K, (s + 1) * k_chunk)), the last one of a direct tail up to K.
+struct KSplit { int steps, splits, k_chunk; bool tail_direct; };
+inline KSplit split_k(const KernelEntry& e, int K, int splits) {
+  KSplit r;
+  r.tail_direct = direct_tail(e) && K % e.kgran != 0;
+  r.steps = r.tail_direct ? K / e.kgran : (K + e.kgran - 1) / e.kgran;
+  r.splits = std::max(1, std::min(splits, r.steps));
+  const int per = (r.steps + r.splits - 1) / r.splits;
+  r.splits = (r.steps + per - 1) / per;
+  r.k_chunk = per * e.kgran;
+  return r;
+}
+
 void model_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
   double best = 1e30;
   int bc = 0, bs = 1;
@@ -675,8 +690,9 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
     // pipeline stages of this geometry along K (BK = 64, or 128 for the "_k128" members)
     if (!k_ok(e, K)) return HGEMM_ERR_BAD_ARG;
     const int kgran = e.kgran;
-    const bool tail_direct = direct_tail(e) && K % kgran != 0;
-    const int ksteps = tail_direct ? K / kgran : (K + kgran - 1) / kgran;   // (direct tail: whole stages; the rest rides on the last split)
+    const KSplit ks0 = split_k(e, K, 1);
+    const bool tail_direct = ks0.tail_direct;
+    const int ksteps = ks0.steps;   // (direct tail: whole stages; the rest rides on the last split)
     // Stream-K (HGEMM_PLAN_STREAMK; the low bits of `splits` are then the number of persistent workgroups): one launch, no
     // combine kernel.  Not available (family without the kernel, too many tiles for the counter block, no workspace): the
     // plan degrades to the geometry's plain data-parallel launch, like a split-K plan without workspace.
@@ -704,9 +720,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
       }
       splits = 1;
     }
-    splits = std::max(1, std::min(splits, ksteps));
-    const int steps_per_split = (ksteps + splits - 1) / splits;
-    splits = (ksteps + steps_per_split - 1) / steps_per_split;  // no empty split
+    splits = split_k(e, K, splits).splits;   // at most one per stage, no empty split
     g.group_m = std::max(1, std::min(group_m, g.tiles_m));
     if (tiles * splits > 0x7fffffffL) return HGEMM_ERR_TOO_LARGE;
     // Split-K: two-pass (slabs + combine kernel) by default; single-launch ("fused") on request, unless the
@@ -729,8 +743,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
         return st;
       }
     }
-    const int per = (ksteps + splits - 1) / splits;
-    g.k_chunk = per * kgran;
+    g.k_chunk = split_k(e, K, splits).k_chunk;   // (splits may have dropped to 1 above: no workspace)
     g.splits = splits;
     const long grid = tiles * splits;
     g.items = (int)grid;
@@ -815,6 +828,13 @@ int hgemm_mi355x_selfcheck_streamk(int tiles, int steps, int G, int min_steps, i
   const StreamK sk = make_streamk(tiles, steps, G, min_steps);
   out[0] = sk_start(sk, w, G);
   out[1] = (x >= 0 && (long)x < (long)tiles * steps) ? sk_owner(sk, x, G) : -1;
+  return HGEMM_OK;
+}
+// how hgemm_mi355x_launch cuts K for (geometry, K, requested split count): out = {stages, splits, k_chunk, direct tail (0 / 1)}
+int hgemm_mi355x_selfcheck_ksplit(int config_id, int K, int splits, int out[4]) {
+  if (config_id < 0 || config_id >= g_num_kernels || K <= 0 || splits < 1 || !out || !k_ok(g_kernel_table[config_id], K)) return HGEMM_ERR_BAD_ARG;
+  const KSplit r = split_k(g_kernel_table[config_id], K, splits);
+  out[0] = r.steps; out[1] = r.splits; out[2] = r.k_chunk; out[3] = r.tail_direct ? 1 : 0;
   return HGEMM_OK;
 }
 unsigned hgemm_mi355x_selfcheck_fastdiv(unsigned n, unsigned d) { return d ? fast_div(n, make_fast_div(d)) : 0xFFFFFFFFu; }

@@ -516,6 +516,42 @@ def test_off_grid_rules_of_round_4(lib):
     assert ratio(r, 64, 16384, 9216, 9160) == 1.0 and ratio(q128, 1332, 3108, 4416, 4480) < 1.03
 
 
+def test_k_is_cut_into_splits_that_cover_it_exactly_once(lib):
+    """How hgemm_mi355x_launch cuts K (hgemm_api.hip: split_k; the kernels' side: map_logical / sq_k_items): for every geometry, a
+    sweep of K (tails included) and every requested split count, the splits are non-empty, all but the last are whole stages, the
+    last one ends at K, a direct tail (families q and r) sits behind at least one whole stage of the last split and is shorter than
+    a stage, and the classic family's partial step is the last step of the last split."""
+    n_cfg = lib.hgemm_mi355x_num_configs()
+    out = (ctypes.c_int * 4)()
+    seen_direct = seen_classic_tail = 0
+    for cid in range(n_cfg):
+        name = lib.hgemm_mi355x_config_name(cid).decode()
+        info = (ctypes.c_int * 8)()
+        lib.hgemm_mi355x_config_info(cid, info)
+        for k in list(range(8, 1100, 8)) + [2104, 4440, 7152, 9160, 16384, 16392]:
+            if not lib.hgemm_mi355x_config_accepts_k(cid, k):
+                assert lib.hgemm_mi355x_selfcheck_ksplit(cid, k, 1, out) != 0
+                continue
+            for want in (1, 2, 3, 5, 8, 16, 64, 1000):
+                assert lib.hgemm_mi355x_selfcheck_ksplit(cid, k, want, out) == 0, (name, k, want)
+                steps, splits, chunk, direct = out[0], out[1], out[2], out[3]
+                stage = chunk // ((steps + splits - 1) // splits)
+                assert 1 <= splits <= min(want, steps) and chunk % stage == 0 and stage in (64, 128, 256), (name, k, want, list(out))
+                assert direct == (1 if (name[0] in "qr" and k % stage) else 0)
+                ranges = [(i * chunk, k if i == splits - 1 else (i + 1) * chunk) for i in range(splits)]
+                assert ranges[0][0] == 0 and ranges[-1][1] == k and all(a < b for a, b in ranges)
+                assert all(ranges[i][1] == ranges[i + 1][0] for i in range(splits - 1))
+                assert all((b - a) % stage == 0 for a, b in ranges[:-1])
+                last = ranges[-1][1] - ranges[-1][0]
+                if direct:
+                    assert last // stage >= 1 and 0 < last % stage < stage and steps == k // stage
+                    seen_direct += 1
+                elif k % stage:
+                    assert name[0] == "t" and steps == -(-k // stage) and last > 0
+                    seen_classic_tail += 1
+    assert seen_direct > 1000 and seen_classic_tail > 1000
+
+
 def test_planner_fuzz_every_answer_is_launchable(lib):
     """Random shapes (aligned and not): the planner always answers with a geometry whose K granularity divides K (or
     a special id), a split count a launch would accept, and a raster group >= 1."""
