@@ -66,51 +66,46 @@ void launch_sp(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingS
     HGEMM_LAUNCH((hgemm_tn_sp_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
 }
 
+// FLAG = 0, or EPI_KTAIL for the "ktail" variants (whole stages through the pipeline + a direct tail: hgemm_kernel_sq.hpp / _rs.hpp)
+template <class CFG, int FLAG>
+void launch_sq_variant(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
+  const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  if (epi == EPI_FUSED)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED | FLAG>), grid, CFG::THREADS, stream, ts, g);
+  else if (epi == EPI_SLAB)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB | FLAG>), grid, CFG::THREADS, stream, ts, g);
+  else if (wide)
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE | FLAG>), grid, CFG::THREADS, stream, ts, g);
+  else
+    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW | FLAG>), grid, CFG::THREADS, stream, ts, g);
+}
+
 template <class CFG>
 void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
-  const bool wide = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-  if constexpr (CFG::MI == 16) {
-    if (g.K % (BK * CFG::KT) != 0) {   // the ktail variants (hgemm_kernel_sq.hpp): whole stages + a direct tail
-      if (epi == EPI_FUSED)
-        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-      else if (epi == EPI_SLAB)
-        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-      else if (wide)
-        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-      else
-        HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-      return;
-    }
+  if constexpr (CFG::MI == 16) {   // (the 32x32x16 members have no K tail: the host never sends them a K that is not whole stages)
+    if (g.K % (BK * CFG::KT) != 0) return launch_sq_variant<CFG, EPI_KTAIL>(g, grid, stream, epi, ts);
   }
+  launch_sq_variant<CFG, 0>(g, grid, stream, epi, ts);
+}
+
+template <class CFG, int FLAG>
+void launch_rs_variant(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
   if (epi == EPI_FUSED)
-    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
+    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_FUSED | FLAG>), grid, CFG::THREADS, stream, ts, g);
   else if (epi == EPI_SLAB)
-    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
-  else if (wide)
-    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_WIDE>), grid, CFG::THREADS, stream, ts, g);
+    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB | FLAG>), grid, CFG::THREADS, stream, ts, g);
   else
-    HGEMM_LAUNCH((hgemm_tn_sq_kernel<CFG, SP_EPI_NARROW>), grid, CFG::THREADS, stream, ts, g);
+    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_C16 | FLAG>), grid, CFG::THREADS, stream, ts, g);
 }
 
 template <class CFG>
 void launch_rs(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
-  if (g.K % CFG::BKS != 0 && epi != EPI_STREAMK) {   // the ktail variants (the host never asks for stream-K with a K tail)
-    if (epi == EPI_FUSED)
-      HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_FUSED | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-    else if (epi == EPI_SLAB)
-      HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-    else
-      HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_C16 | EPI_KTAIL>), grid, CFG::THREADS, stream, ts, g);
-    return;
-  }
-  if (epi == EPI_STREAMK)
+  if (epi == EPI_STREAMK)   // (the host never asks for stream-K with a K tail)
     HGEMM_LAUNCH((hgemm_tn_rs_sk_kernel<CFG>), grid, CFG::THREADS, stream, ts, g);
-  else if (epi == EPI_FUSED)
-    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_FUSED>), grid, CFG::THREADS, stream, ts, g);
-  else if (epi == EPI_SLAB)
-    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_SLAB>), grid, CFG::THREADS, stream, ts, g);
+  else if (g.K % CFG::BKS != 0)
+    launch_rs_variant<CFG, EPI_KTAIL>(g, grid, stream, epi, ts);
   else
-    HGEMM_LAUNCH((hgemm_tn_rs_kernel<CFG, EPI_C16>), grid, CFG::THREADS, stream, ts, g);
+    launch_rs_variant<CFG, 0>(g, grid, stream, epi, ts);
 }
 
 template <class CFG>
