@@ -198,7 +198,7 @@ struct GemmArgs {
   // Single-launch split-K (EPI_FUSED): one arrival counter per output tile (zero before the launch, reset
   // by the last arriver) and compact per-item slabs partial[item][BM*BN] in the kernel's own lane order.
   unsigned* counters;
-  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE); family r: bit 1 K stagger per XCD instead of per tile
+  int flags;       // bit 0: non-temporal fp16 C stores (HGEMM_PLAN_NT_STORE); bit 1 (HGEMM_PLAN_XCD_STAGGER) family r: K stagger per XCD instead of per tile, family q: the kstagger variant
                    // (HGEMM_PLAN_RS_XCD_STAGGER), bit 2 non-temporal loads of the streamed operand (HGEMM_PLAN_RS_NT_LOADS)
 #if HGEMM_FASTDIV
   RasterDiv rd;    // multipliers for the raster map's divisions (set_raster_div on the host, after the fields above are final)
@@ -299,6 +299,9 @@ constexpr int EPI_STREAMK = 3; // stream-K: one persistent launch over the tile-
 // multiple of the geometry's stage depth -- whole stages through the pipeline, the rest by direct_k_tail.  A variant of its own,
 // so the kernels every K % stage == 0 launch runs keep their instruction streams.
 constexpr int EPI_KTAIL = 8;
+// Kernel-template flag (family q, round 5): the "kstagger" variant -- the workgroups of XCD x start every work item's K walk at
+// stage x * nk / 8 and wrap (plan flag HGEMM_PLAN_XCD_STAGGER).  A variant of its own for the same reason as EPI_KTAIL.
+constexpr int EPI_KSTAGGER = 16;
 
 // Compile-time geometry of one kernel instantiation.
 template <int BM_, int BN_, int WM_, int WN_, int MI_, int NBUF_>

@@ -85,8 +85,17 @@ struct CfgSP : Cfg<BM_, BN_, WM_, WN_, MI_, 2> {
 // MFMAs stay between them.  No s_nop: with one wave per SIMD the 16-cycle MFMA issue interval leaves
 // ~3 issue slots, and the fragment operands are only ever written by ds_read (waited for by
 // lgkmcnt), never by a VALU instruction.
+// N = 256 for every member that runs one workgroup per CU.  Round 5: a member whose LDS footprint lets TWO workgroups share a CU
+// reserves exactly its accumulators, so that its waves stay within 256 registers and two of them fit a SIMD (round 3 launched
+// 512 workgroups of q128x128 with all 256 AGPRs reserved -- 356 registers per wave, so only one workgroup per CU was ever
+// resident and the other half queued: its "two workgroups per CU lose" figure measured that, not co-residency).
+template <int N = 256>
 __device__ __forceinline__ void sp_reserve_agprs() {
-  asm volatile("" ::: "a0", "a63", "a127", "a128", "a191", "a255");
+  static_assert(N == 256 || N == 128 || N == 96 || N == 64, "accumulator count of a two-resident member");
+  if constexpr (N == 256) asm volatile("" ::: "a0", "a63", "a127", "a128", "a191", "a255");
+  else if constexpr (N == 128) asm volatile("" ::: "a0", "a63", "a127");
+  else if constexpr (N == 96) asm volatile("" ::: "a0", "a63", "a95");
+  else asm volatile("" ::: "a0", "a63");
 }
 __device__ __forceinline__ void sp_mfma(int n, const f16x8& a, const f16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(n * 4), "n"(n * 4 + 3));
@@ -395,9 +404,12 @@ __device__ __forceinline__ void sp_epilogue_staged(const GemmArgs& g, int m_wave
   };
   auto store_group = [&](int k, bool writes_behind) {
     const int i = k / NG, gg = k % NG, b = k & 1;
-    // the two reads are older than the (up to four) writes of the next group: in-order return
-    if (writes_behind) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(rb[b][0]), "+v"(rb[b][1])::"memory");
-    else               asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[b][0]), "+v"(rb[b][1])::"memory");
+    // lgkmcnt(0), not a counted wait past the (up to four) ds_writes of the next group: LDS returns in order, but scalar loads
+    // share the counter and return out of order -- a counted wait is only as good as the proof that no s_load is in the window
+    // (rounds 3-4 audited the ISA for that instead; round 5: the writes have long retired when the read-back data arrives, the
+    // plain wait costs nothing measurable, profiles/r05_*).
+    (void)writes_behind;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[b][0]), "+v"(rb[b][1])::"memory");
     if (HGEMM_DBG(g, 2)) return;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {

@@ -124,6 +124,13 @@ struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, MI_, 2> {
   static_assert(P + 1 + STA * (NJB + NFA) <= T && Q + 1 + STB * (NJA + NFB) <= T, "slot plan does not fit the interval");
   static_assert(Base::FM * Base::FN * ACC <= 256, "accumulators live in a0..a255");
   static_assert(LDS_BYTES + 64 <= 160 * 1024, "LDS budget");
+  // AGPRs the kernel descriptor reserves: all 256 (one wave per SIMD owns the file), or exactly the accumulators when the LDS
+  // footprint admits two workgroups per CU (sp_reserve_agprs)
+  // WGS = 2: "two-resident" member (round 5) -- its two stages fit twice into the CU's 160 KiB, its waves into half a SIMD's
+  // register file: the plain-epilogue kernels then declare the stages and nothing else (no vote word, no staged epilogue), and the
+  // host launches 512 persistent workgroups: one workgroup's epilogue runs under the other's K loop without any schedule of ours.
+  static constexpr int WGS = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int AGPRS = WGS == 2 ? Base::FM * Base::FN * ACC : 256;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -247,17 +254,23 @@ __device__ __forceinline__ void sq_issue_piece(__amdgpu_buffer_rsrc_t rs, const 
 // covers the one wait state an LDS-DMA needs behind an M0 write.
 // `cont`: the previous piece of this window was idx - 1 in the same sub-tile, so M0 only moves on by one row block of the
 // four waves (one instruction instead of an address computation + a move).
+// Both statements name M0 as clobbered (round 5): the compiler then models the write -- it may merge two identical M0
+// initialisations of its own only when nothing in between defines M0 -- instead of the ISA audit being the only guard.  clang
+// warns that M0 is a reserved register it will not preserve across the statement: not preserving it is the point.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <class CFG, int OP>
 __device__ __forceinline__ void sq_piece_m0(uint32_t wave_stage_lds, int idx, bool cont) {
   constexpr int POP = OP == 0 ? CFG::PA : CFG::PB;
   const int sub = idx / POP, p = (OP == 0 ? 0 : CFG::PA) + idx % POP;
   if (cont && idx % POP != 0) {
-    asm volatile("s_add_u32 m0, m0, %0" ::"n"(CFG::NW * 1024));
+    asm volatile("s_add_u32 m0, m0, %0" ::"n"(CFG::NW * 1024) : "m0");
   } else {
     // (the sum as an "s" operand: the piece index is a constant only after unrolling, too late for an immediate constraint)
-    asm volatile("s_mov_b32 m0, %0" ::"s"(wave_stage_lds + (uint32_t)(sub * CFG::SUB_BYTES + p * CFG::NW * 1024)));
+    asm volatile("s_mov_b32 m0, %0" ::"s"(wave_stage_lds + (uint32_t)(sub * CFG::SUB_BYTES + p * CFG::NW * 1024)) : "m0");
   }
 }
+#pragma clang diagnostic pop
 template <class CFG, int OP>
 __device__ __forceinline__ void sq_piece_load(__amdgpu_buffer_rsrc_t rs, const uint32_t (&voff)[OP == 0 ? CFG::PA : CFG::PB], int idx,
                                               uint32_t kbyte) {
@@ -387,7 +400,12 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
     const unsigned range_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(rem_ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)rem_)); \
     if ((OP) == 0) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
     else           rsB = __builtin_amdgcn_make_buffer_rsrc((void*)uni, 0, (int)range_, 0x00020000);            \
-    cur[OP].kbyte = (uint32_t)nxt_kb;                                                                          \
+    /* kstagger variant: this XCD's workgroups enter the item's K range stag_ stages in and wrap behind its last stage;   \
+       BOTH streams of an item take the same rotation (the cursor is all that knows about it: whatever is issued for a      \
+       stream position reads (descriptor, kbyte) of the cursor, early and late pieces alike) */                            \
+    const int stag_ = STAG ? (int)(((uint32_t)(blockIdx.x & (NUM_XCD - 1)) * (uint32_t)nxt_nk) >> 3) : 0;                   \
+    cur[OP].kbyte0 = (uint32_t)nxt_kb; cur[OP].kwrap = nxt_nk - stag_;                                         \
+    cur[OP].kbyte = (uint32_t)nxt_kb + (uint32_t)stag_ * (uint32_t)(CFG::KT * ROW_BYTES);                      \
     cur[OP].item = (ITEM); cur[OP].kt = 0; cur[OP].nk = nxt_nk;                                                \
   } while (0)
 
@@ -396,6 +414,7 @@ __device__ __forceinline__ void sq_interval(const f16x8 (&af)[CFG::NFA], const f
   do {                                                                                       \
     ++cur[OP].kt;                                                                            \
     cur[OP].kbyte += CFG::KT * ROW_BYTES;                                                    \
+    if (STAG && cur[OP].kt == cur[OP].kwrap) cur[OP].kbyte = cur[OP].kbyte0;   /* (kwrap == nk without a stagger: never reached) */ \
   } while (0)
 
 // Move a stream one K-step on; past the last step of the last item it stays put (the branch-free DMA then
@@ -444,26 +463,37 @@ __device__ __forceinline__ int sq_k_items(const GemmArgs& g, const TileCoord& tc
 // already hold the NEXT item's first tile (the streams cross item seams), Z and V are dead: the tail's fragments take their
 // registers.  Its loads queue behind the LDS-DMA pieces in flight; waiting for them (vmcnt is in order) only lands the
 // next item's tiles early.
+// + EPI_KSTAGGER (round 5): the variant for the one-round, lock-step plans (one tile per CU, every workgroup at the same K offset
+// of rows 16-32 KiB apart: which HBM channels collide depends on the box, DESIGN.md sections 4.12 / 6.5): the workgroups of XCD x
+// walk every work item's stages in the order x nk / 8, ..., nk - 1, 0, ..., x nk / 8 - 1.  Inside an XCD the workgroups stay in
+// lock-step (they share operand panels in its L2), the eight XCDs are nk / 8 stages apart.  Round 3's knob of the same intent
+// offset the two streams separately and was wrong for every non-square member; here the rotation lives in the stream cursor
+// (SQ_LOAD_ITEM / SQ_STEP_CURSOR), which both streams of an item derive from the same (XCD, stage count).  The summation order of
+// a tile then depends on the XCD that computes it: exact on 0/1 inputs, deterministic per plan (raster group included) on N(0,1).
 template <class CFG, int EPI_>
 __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArgs g) {
   prefetch_kernargs<sizeof(GemmArgs)>();
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int EPI = EPI_ & 7;
   constexpr bool KTAIL = (EPI_ & EPI_KTAIL) != 0;
+  constexpr bool STAG = (EPI_ & EPI_KSTAGGER) != 0;
   static_assert(!KTAIL || CFG::MI == 16, "the K tail is built from 16x16x32 fragments");
+  static_assert(!(KTAIL && STAG), "the kstagger variant takes whole stages only (the host drops the flag when K has a tail)");
   constexpr int BM = CFG::BM, BN = CFG::BN, FM = CFG::FM, FN = CFG::FN, NJ = CFG::NJ, MI = CFG::MI;
   constexpr int NFA = CFG::NFA, NFB = CFG::NFB;
   constexpr int NQ = CFG::ACC / 4;              // f32x4 quads per accumulator tile
 
   // the two stages + one word for the single-launch split-K vote (ONE LDS object, see hgemm_kernel_sp.hpp)
-  constexpr bool STAGED = EPI == SP_EPI_WIDE && sp_staged_ok<CFG>(CFG::LDS_BYTES);   // + 4 KiB per wave for the epilogue
+  constexpr bool STAGED = EPI == SP_EPI_WIDE && CFG::WGS == 1 && sp_staged_ok<CFG>(CFG::LDS_BYTES);   // + 4 KiB per wave for the epilogue
 #ifdef HGEMM_TIMELINE
   constexpr int TL_EXTRA = 64;   // measurement build: eight more stamp slots behind everything else
+  constexpr int FLAG_BYTES = 64;
 #else
   constexpr int TL_EXTRA = 0;
+  constexpr int FLAG_BYTES = (CFG::WGS == 2 && EPI != SP_EPI_FUSED) ? 0 : 64;   // (two-resident members: exactly the stages, see CfgSQ::WGS)
 #endif
   constexpr int STAGED_BYTES = STAGED ? CFG::NW * SP_STAGED_BYTES_PER_WAVE : 0;
-  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + 64 + STAGED_BYTES + TL_EXTRA];
+  __shared__ __attribute__((aligned(1024))) char smem[CFG::LDS_BYTES + FLAG_BYTES + STAGED_BYTES + TL_EXTRA];
 
   const int tid  = threadIdx.x;
   // (measurement build: stamps go to the 64 scratch bytes behind the stages; slot 0 doubles as the fused vote word,
@@ -489,7 +519,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   const int a_base_off = wave_m * CFG::TM * ROW_BYTES;
   const int b_base_off = BM * ROW_BYTES + wave_n * CFG::TN * ROW_BYTES;
 
-  sp_reserve_agprs();
+  sp_reserve_agprs<CFG::AGPRS>();
 
   // ---- the two LDS-DMA streams (A: three tiles ahead of the MFMAs, B: two) ---------------------------------
   __amdgpu_buffer_rsrc_t rsA, rsB;
@@ -503,7 +533,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   for (int q = 0; q < CFG::PA; ++q) voffA[q] = ((uint32_t)((wave + q * CFG::NW) * 8 + (lane >> 3)) * (uint32_t)g.lda + chunk0 * 8u) * 2u;
 #pragma unroll
   for (int q = 0; q < CFG::PB; ++q) voffB[q] = ((uint32_t)((wave + q * CFG::NW) * 8 + (lane >> 3)) * (uint32_t)g.ldb + chunk0 * 8u) * 2u;
-  struct Cursor { uint32_t kbyte; int item, kt, nk; } cur[2];
+  struct Cursor { uint32_t kbyte; int item, kt, nk; uint32_t kbyte0; int kwrap; } cur[2];   // (kbyte0, kwrap: kstagger variant only)
   int nxt_item = -1, nxt_m0 = 0, nxt_n0 = 0, nxt_kb = 0, nxt_nk = 0;   // tile coordinates of the item the streams enter next
   SQ_LOAD_ITEM(0, 0);
   SQ_LOAD_ITEM(1, 0);

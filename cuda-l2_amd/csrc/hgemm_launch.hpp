@@ -84,6 +84,8 @@ template <class CFG>
 void launch_sq(const GemmArgs& g, int grid, hipStream_t stream, int epi, TimingSlot ts) {
   if constexpr (CFG::MI == 16) {   // (the 32x32x16 members have no K tail: the host never sends them a K that is not whole stages)
     if (g.K % (BK * CFG::KT) != 0) return launch_sq_variant<CFG, EPI_KTAIL>(g, grid, stream, epi, ts);
+    // plan flag HGEMM_PLAN_XCD_STAGGER (GemmArgs::flags bit 1): whole stages only, the 16x16x32 members only
+    if (g.flags & 2) return launch_sq_variant<CFG, EPI_KSTAGGER>(g, grid, stream, epi, ts);
   }
   launch_sq_variant<CFG, 0>(g, grid, stream, epi, ts);
 }

@@ -73,8 +73,8 @@ const KernelEntry g_kernel_table[] = {
 #define HGEMM_SQ_NAME_1_32(BM, BN, WM, WN) "q" HGEMM_STR(BM) "x" HGEMM_STR(BN) "_w" HGEMM_STR(WM) "x" HGEMM_STR(WN) "_m32"
 #define HGEMM_SQ(G, BM, BN, WM, WN, KT, MI)                                                                     \
   {HGEMM_SQ_NAME_##KT##_##MI(BM, BN, WM, WN), BM, BN, WM, WN, MI, 2, CfgSQ<BM, BN, WM, WN, KT, MI>::THREADS,      \
-   CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64, &launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>,                      \
-   256 * (160 * 1024 / (CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + 64)), true, 64 * KT, MI == 16, 0},
+   CfgSQ<BM, BN, WM, WN, KT, MI>::LDS_BYTES + (CfgSQ<BM, BN, WM, WN, KT, MI>::WGS == 2 ? 0 : 64), &launch_sq<CfgSQ<BM, BN, WM, WN, KT, MI>>, \
+   256 * CfgSQ<BM, BN, WM, WN, KT, MI>::WGS, true, 64 * KT, MI == 16, 0},
 #include "hgemm_configs.def"
 #undef HGEMM_CFG
 #undef HGEMM_SP

@@ -323,12 +323,16 @@ static int cmd_check(const std::vector<Shape>& shapes) {
         continue;   // --configs: only these (the special ids are "generic" / "ragged")
       // stream-K forms (geometries that have the kernel): one resident wave of workgroups, and small odd grids that cut tiles
       // at odd stages and give every workgroup several segments
-      for (int splits : {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED, HGEMM_PLAN_STREAMK, 5 | HGEMM_PLAN_STREAMK,
-                         37 | HGEMM_PLAN_STREAMK, 300 | HGEMM_PLAN_STREAMK,
-                         // family r's plan flags (K stagger per XCD, non-temporal loads of the streamed operand), alone and combined
-                         1 | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS, 2 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_RS_XCD_STAGGER,
-                         3 | HGEMM_PLAN_RS_NT_LOADS, 37 | HGEMM_PLAN_STREAMK | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS}) {
-        if ((splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS)) && (c < 0 || hgemm_mi355x_config_name(c)[0] != 'r')) continue;
+      const char fam = c >= 0 ? cname[0] : ' ';
+      std::vector<int> forms = {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED, HGEMM_PLAN_STREAMK, 5 | HGEMM_PLAN_STREAMK,
+                                37 | HGEMM_PLAN_STREAMK, 300 | HGEMM_PLAN_STREAMK};
+      if (fam == 'r')   // family r's plan flags (K stagger per XCD, non-temporal loads of the streamed operand), alone and combined
+        forms.insert(forms.end(), {1 | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS, 2 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_RS_XCD_STAGGER,
+                                   3 | HGEMM_PLAN_RS_NT_LOADS, 37 | HGEMM_PLAN_STREAMK | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS});
+      if (fam == 'q')   // family q's kstagger variant (round 5): plain, with NT stores, two-pass and single-launch split-K
+        forms.insert(forms.end(), {1 | HGEMM_PLAN_XCD_STAGGER, 1 | HGEMM_PLAN_XCD_STAGGER | HGEMM_PLAN_NT_STORE, 3 | HGEMM_PLAN_XCD_STAGGER,
+                                   4 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_XCD_STAGGER});
+      for (int splits : forms) {
         const bool sk = (splits & HGEMM_PLAN_STREAMK) != 0;
         const int sp = sk ? 2 : (splits & HGEMM_SPLITK_MASK);   // (sp > 1: run twice, one raster group)
         if (sk && (c < 0 || hgemm_mi355x_config_streamk(c) <= 0)) continue;
@@ -375,7 +379,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     if (g_config_filter.empty() || std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) != g_config_filter.end())
       printf(" %s", cname);
   }
-  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, raster groups 1 4\n");
+  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger, raster groups 1 4\n");
   printf("check: %d runs, %d failures (bit-exact against the exact integer result of 0/1 inputs)\n", runs, failures);
   return failures ? 1 : 0;
 }

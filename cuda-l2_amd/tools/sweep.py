@@ -5,7 +5,8 @@ the reference's eval_results CSV format plus per-shape TFLOP/s and the geomean s
 The reference publishes only the merged CSVs (eval_results/*.csv) and has no driver; a single GEMM
 never spans GPUs, so multi-GPU = independent shards, no collective:
 
-    rank i of G evaluates shapes[i::G] on GPU i (one process per GPU), results meet on the filesystem.
+    rank i of G evaluates its cost-balanced share of the shapes (shard(): longest-processing-time-first on the recorded
+    per-shape costs) on GPU i (one process per GPU), results meet on the filesystem.
 
   python tools/sweep.py run   --out results --acc_precise fp32 --mode offline [--gpus 8] [--shapes-file f]
   python tools/sweep.py run   --inprocess ...   same metric without the per-baseline process churn (tools/sweep_inprocess.py)
@@ -44,12 +45,50 @@ MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md
 HBM_PEAK_TBPS = 8.0             # HBM3E spec
 
 
+_COSTS = None
+
+
+def recorded_costs() -> dict:
+    """Seconds per shape as the round-4 whole-grid sweep recorded them (tools/sweep_costs_r04.json: time-boxed loop + autotune
+    search of the in-process driver)."""
+    global _COSTS
+    if _COSTS is None:
+        path = PKG_DIR / "tools" / "sweep_costs_r04.json"
+        _COSTS = json.loads(path.read_text())["costs"] if path.exists() else {}
+    return _COSTS
+
+
+def estimated_cost(mnk: str) -> float:
+    """Wall seconds one shape costs a rank: the recorded figure for a grid shape, else fixed time boxes + what grows with the
+    shape (operand generation and the first calls scale with bytes / flops)."""
+    c = recorded_costs().get(mnk)
+    if c is not None:
+        return float(c)
+    m, n, k = map(int, mnk.split("_"))
+    return 0.26 + 2.0 * m * n * k / 2.5e13 + 2.0 * (m * k + k * n + m * n) / 3e9
+
+
 def shard(shapes: list[str], rank: int, world: int) -> list[str]:
-    """Round-robin partition: every shape costs ~the same wall time (fixed warm-up + benchmark seconds),
-    so shapes[rank::world] balances the ranks; the union over ranks is exactly `shapes`."""
+    """Cost-sorted partition ("sort shapes by estimated eval cost"): longest-processing-time-first -- shapes
+    in decreasing estimated cost, each to the rank with the least load so far (ties: the lower rank) -- so the slowest rank's
+    wall, the denominator of the multi-GPU aggregate, stays within a shape's cost of the mean.  Deterministic: every rank computes
+    the same assignment; the union over ranks is exactly `shapes`; a rank's shapes come back in the order of `shapes` (resumable
+    runs and records stay in grid order).  Round-robin, what rounds 1-4 did, left the ranks 0.1-1.5 % apart on the recorded costs;
+    this leaves < 0.1 %."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world {world}")
-    return shapes[rank::world]
+    order = sorted(range(len(shapes)), key=lambda i: (-estimated_cost(shapes[i]), i))
+    load = [0.0] * world
+    owner = [0] * len(shapes)
+    for i in order:
+        r = min(range(world), key=lambda x: (load[x], x))
+        owner[i] = r
+        load[r] += estimated_cost(shapes[i])
+    return [s for i, s in enumerate(shapes) if owner[i] == rank]
+
+
+def shard_loads(shapes: list[str], world: int) -> list[float]:
+    return [sum(map(estimated_cost, shard(shapes, r, world))) for r in range(world)]
 
 
 def flops(mnk: str) -> float:
@@ -268,7 +307,7 @@ def main(argv=None):
     if args.command == "plan":
         for r in range(world):
             mine = shard(shapes, r, world)
-            print(f"rank {r}: {len(mine)} shapes, {sum(map(flops, mine)):.3e} flop per pass")
+            print(f"rank {r}: {len(mine)} shapes, {sum(map(flops, mine)):.3e} flop per pass, estimated {sum(map(estimated_cost, mine)):.1f} s")
         return None
     if args.command == "run" and args.inprocess:
         status = sweep_inprocess.run(args, shard(shapes, rank, world), rank, gpu)

@@ -5,7 +5,7 @@ per baseline (7 per shape, each importing torch and the extension), which costs 
 single GEMM is timed: 1000 shapes x 2 accumulate trees x 2 modes = ~70 GPU-hours.  This driver keeps the
 MEASUREMENT of the reference and drops the process churn:
 
-  * one process per (GPU, accumulate tree, mode) loops over its shard of the shape list (shapes[rank::world],
+  * one process per (GPU, accumulate tree, mode) loops over its shard of the shape list (tools/sweep.py shard(): cost-sorted,
     as tools/sweep.py), with ONE prebuilt `hgemm_lib` extension (the per-shape kernel files only pin the plan
     the library's tuned table already holds, so the generic entry point runs the same plan);
   * per shape and per baseline X the inner loop is the reference's (benchmarking_offline.py:115-137 /

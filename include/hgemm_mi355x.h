@@ -93,6 +93,13 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  *   not push the shared operand's slices out of the L2 (what hipBLASLt's kernels do on the skinny shapes: NTA / NTB). */
 #define HGEMM_PLAN_RS_XCD_STAGGER 0x80000
 #define HGEMM_PLAN_RS_NT_LOADS    0x100000
+/* The same bit for the "q" geometries (round 5; 16x16x32 members, K a whole number of pipeline stages -- ignored otherwise):
+ * HGEMM_PLAN_XCD_STAGGER selects the "kstagger" kernel variant -- the workgroups of XCD x walk every work item's K stages in the
+ * rotated order x nk / 8, ..., nk - 1, 0, ..., x nk / 8 - 1 (family q has no stagger without the flag).  For the one-round plans
+ * whose 256 workgroups otherwise read the same K offset of rows 16-32 KiB apart at the same time: the reference's H100 tree
+ * gets the same effect from stream-K start offsets (kernels/h100_F32F16F16F32/16384_512_2048.cu:71-73).  Exactness / determinism
+ * as above. */
+#define HGEMM_PLAN_XCD_STAGGER HGEMM_PLAN_RS_XCD_STAGGER
 
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)

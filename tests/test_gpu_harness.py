@@ -131,3 +131,55 @@ def test_defense_audit_passes_on_the_shipped_op(kernel):
     big_c = torch.zeros((2048, 2048), dtype=torch.half, device="cuda")
     passed, msg, _ = defense.check_stream_injection(lambda: sneaky(big_a, big_b, None, big_c))
     assert not passed and "Stream injection detected" in msg
+
+
+def test_fp16_torch_module_builds_imports_and_passes_the_correctness_flow(tmp_path):
+    """VERDICT r4 gap: the `cuda_l2_mi355x_fp16` torch module (pybind/hgemm_mi355x_fp16.cc) was only ever compiled.  Built and
+    imported here in its own process (one process can hold only one `hgemm_lib`), for BASELINE.json configs[2]'s shape: the 15
+    names, one call on N(0,1) operands within tolerance, the fp16 error texts, then the reference's 0/1 flow."""
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from harness_common import load_kernel
+from tools.utils import as_col_major
+import zero_one_correctness_check as zo
+k = load_kernel("4096_4096_4096", "fp16", "mi355x", %r)
+names = %r + ["cuda_l2_mi355x_fp16"]
+assert all(callable(getattr(k.module, n)) for n in names), "missing names"
+assert k.cuda_l2_func.__name__ == "cuda_l2_mi355x_fp16" and k.padding == (0, 0, 0)
+assert not hasattr(k.module, "cuda_l2_mi355x_fp32")
+a = torch.randn(4096, 4096, dtype=torch.half, device="cuda"); b = torch.randn(4096, 4096, dtype=torch.half, device="cuda")
+c = torch.full((4096, 4096), float("nan"), dtype=torch.half, device="cuda")
+assert k.cuda_l2_func(a, b, as_col_major(b), c) is None
+torch.cuda.synchronize()
+ref = a[:256].float() @ b.float()
+rel = ((c[:256].float() - ref).abs().max() / ref.abs().max()).item()
+assert rel <= 1e-3, rel
+assert not torch.isnan(c).any()
+try:
+    k.cuda_l2_func(a.float(), b, as_col_major(b), c); raise SystemExit("no dtype error")
+except RuntimeError as e:
+    assert "values must be torch::kHalf" in str(e), str(e)
+ok, msg, res = zo.run_correctness_check(k, 4096, 4096, 4096, num_iterations=2, max_seconds=60)
+assert ok, msg
+assert res["avg_cuda_l2_mi355x_fp16_diff"] == 0.0 and res["avg_hgemm_cublaslt_auto_tuning_tn_diff"] == 0.0
+print("FP16_MODULE_OK", json.dumps({"rel": rel, "iters": res["num_iterations"], "so": k.module.__file__}))
+""" % (str(PKG), str(tmp_path), NAMES)
+    res = subprocess.run([sys.executable, "-c", code], cwd=PKG, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "FP16_MODULE_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_eval_one_file_end_to_end(tmp_path):
+    """The reference's whole per-shape flow (eval_one_file.sh:16-110) on BASELINE.json configs[1]: correctness check first, the
+    self-audit, seven baselines in shuffled order, one process each, then the summary -- short time boxes."""
+    base = tmp_path / "64_4096_64"
+    res = subprocess.run(["bash", str(PKG / "eval_one_file.sh"), "--mnk", "64_4096_64", "--acc_precise", "fp32", "--device_type", "mi355x",
+                          "--warmup_seconds", "0.2", "--benchmark_seconds", "0.5", "--base_dir", str(base), "--gpu_device_id", "0",
+                          "--mode", "offline", "--defense"], capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-2500:] + res.stderr[-2500:]
+    assert "All benchmarks completed successfully!" in res.stdout
+    check = json.loads((base / "zero_one_correctness_check_result.json").read_text())
+    assert check["success"] and check["result"]["avg_cuda_l2_mi355x_fp32_diff"] == 0.0
+    assert len(list(base.glob("benchmark_result_*.json"))) == 7
+    rows = json.loads((base / "summary.json").read_text())
+    assert len(rows) == 10 and all(r["Speedup"] > 0 for r in rows if "Speedup" in r)

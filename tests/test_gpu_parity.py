@@ -326,6 +326,28 @@ def test_randn_tolerance_at_4096_cubed(g, oracle):
     assert np.array_equal(again.view(np.uint16), g.gemm(a, b, "fp32").view(np.uint16))  # run-to-run identical
 
 
+@pytest.mark.parametrize("mnk,entry", [((64, 4096, 64), "fp32"), ((512, 4096, 4096), "fp32"), ((4096, 4096, 4096), "fp16")])
+def test_baseline_sizes_whole_tile_normal_inputs_against_the_cpu_expression(g, oracle, mnk, entry):
+    """The three BASELINE.json shapes on N(0,1) operands, EVERY element of C (not a row sample) against the reference's own
+    oracle expression evaluated on the host -- (a.float() @ b.float()).half(), zero_one_correctness_check.py:85-90 -- within
+    the north-star tolerance (1e-3 relative for fp32 accumulate; the fp16 entry accumulates in fp32 too, so the same bound
+    instead of 1e-2), plus a per-element bound: no element further than 2 fp16 ulps of the row's largest magnitude."""
+    m, n, k = mnk
+    rng = np.random.default_rng(7 * m + 3 * n + k)
+    a = rng.standard_normal((m, k), dtype=np.float32).astype(np.float16)
+    b = rng.standard_normal((k, n), dtype=np.float32).astype(np.float16)
+    ref32 = torch.matmul(torch.from_numpy(a).float(), torch.from_numpy(b).float())
+    ref = ref32.half().numpy()
+    got = g.gemm(a, b, entry)
+    assert got.shape == ref.shape and not np.isnan(got).any()
+    assert oracle.relative_error(got, ref32.numpy()) <= REL_TOL
+    diff = np.abs(got.astype(np.float32) - ref.astype(np.float32))
+    scale = np.abs(ref.astype(np.float32)).max(axis=1, keepdims=True)
+    assert (diff <= scale * 2.0 ** -9).all()          # 2 ulps of the row maximum (fp16: 10 mantissa bits)
+    # different summation orders round differently in the last place only: almost every element is bit-identical
+    assert (got.view(np.uint16) == ref.view(np.uint16)).mean() > 0.9
+
+
 def test_split_k_is_deterministic_and_within_tolerance(g, oracle):
     m, n, k = 128, 256, 16384
     rng = np.random.default_rng(6)

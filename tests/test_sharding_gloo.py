@@ -49,7 +49,7 @@ def test_two_rank_sharding_and_reduction():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert len(gathered[0]) == 4 and len(gathered[1]) == 3
+    assert {len(gathered[0]), len(gathered[1])} == {3, 4} and not set(gathered[0]) & set(gathered[1])
     assert sorted(gathered[0] + gathered[1]) == sorted(f"{64 * (i + 1)}_128_64" for i in range(7))
     assert abs(elapsed - 0.020) < 1e-9      # max over ranks
     assert flops == total                    # whole-job work = sum over ranks
@@ -58,7 +58,7 @@ def test_two_rank_sharding_and_reduction():
 def test_two_rank_cpu_sweep_run_then_merge(tmp_path):
     """tools/sweep.py end to end on two ranks without a GPU (BASELINE config 1, the harness's --device cpu plumbing path):
     launched the way the driver launches a multi-GPU job (torch.distributed.run, 127.0.0.1 rendezvous), every rank
-    evaluates shapes[rank::2] through benchmarking_offline.py, the results meet on the filesystem and `merge` reads BOTH
+    evaluates its shard through benchmarking_offline.py, the results meet on the filesystem and `merge` reads BOTH
     rank status files: ranks == 2, max-over-ranks wall, sum 2MNK / that wall and the CPU column are all there."""
     import json
     import subprocess
@@ -90,3 +90,34 @@ def test_two_rank_cpu_sweep_run_then_merge(tmp_path):
     assert cpu["shapes"] == 6 and cpu["flop_weighted_tflops"] > 0 and cpu["os_cpu_count"] >= 1
     # a second sweep (other accumulate tree) keeps its own status files: nothing is overwritten
     assert not (out / "rank0_status.json").exists()
+
+
+def test_cost_sorted_sharding_balances_the_grid():
+    """SURVEY.md section 8e / VERDICT r4 item 9: the shard assignment is cost-sorted (longest-processing-time-first on the per-shape
+    wall times the round-4 sweep recorded), a partition, deterministic, and leaves the ranks within 5 % of each other on the
+    1000-shape grid for 2, 4 and 8 GPUs -- the slowest rank's wall is the denominator of the multi-GPU aggregate."""
+    sys.path[:0] = [str(REPO / "cuda-l2_amd")]
+    from tools import sweep
+    from tools.gen_shape_kernels import grid_shapes
+
+    shapes = grid_shapes()
+    assert len(shapes) == 1000 and all(s in sweep.recorded_costs() for s in shapes)
+    for world in (1, 2, 4, 8):
+        parts = [sweep.shard(shapes, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == sorted(shapes) and sum(map(len, parts)) == len(shapes)      # a partition
+        assert parts == [sweep.shard(shapes, r, world) for r in range(world)]                        # deterministic
+        for part in parts:                                                                           # grid order kept
+            idx = [shapes.index(s) for s in part[:50]]
+            assert idx == sorted(idx)
+        loads = sweep.shard_loads(shapes, world)
+        assert max(loads) <= 1.05 * (sum(loads) / world), (world, loads)
+        assert max(loads) - min(loads) <= max(map(sweep.estimated_cost, shapes))                     # LPT's bound
+    # shapes off the grid fall back to the analytic estimate and still balance (costs differ by 100x here)
+    odd = [f"{64 * i}_{4096 if i % 3 else 128}_{8192 if i % 2 else 64}" for i in range(1, 41)]
+    loads = sweep.shard_loads(odd, 4)
+    assert max(loads) <= 1.10 * (sum(loads) / 4)
+    try:
+        sweep.shard(shapes, 2, 2)
+        raise AssertionError("rank outside world must raise")
+    except ValueError:
+        pass
