@@ -16,14 +16,15 @@ value = total FLOPs of all ranks / max-over-ranks time, in TFLOP/s.  A single GE
 N independent replicas (weak scaling, no collective on the data path).
 
 Extra objects on the JSON line:
-  roofline      the workload's kernel (MFMA-bound): 2MNK / launch duration vs the 2.5 PFLOP/s dense fp16 MFMA peak.  Two
-                clocks are taken live in the timed region and BOTH are upper bounds of the kernel's duration: (i) HIP events
-                that ride on the dispatch packets of every 16th launch (on the launch stream, hipExtLaunchKernel start /
-                stop events) -- in a back-to-back stream a dispatch's start event fires while its predecessor is still
-                draining, so their mean overstates the kernel by ~1 %; (ii) the rank's wall clock of the timed region
-                divided by the launches in it, which includes the ~2 us between launches.  `launch_us` = the smaller of the
-                two, `clock` names it, both are reported: `achieved` / `frac` are therefore LOWER bounds of what the kernel
-                sustains (the committed rocprofv3 --kernel-trace --stats summary of the same command is the third clock).
+  roofline      the workload's kernel (MFMA-bound): 2MNK / launch duration vs the 2.5 PFLOP/s dense fp16 MFMA peak.  `launch_us`
+                is ONE clock: the mean of HIP events that ride on the dispatch packets of every 16th launch of the timed region
+                (on the launch stream, hipExtLaunchKernel start / stop events).  In a back-to-back stream a dispatch's start
+                event fires while its predecessor is still draining, so the mean overstates the kernel by ~1 % and `achieved` /
+                `frac` understate it slightly.  `wall_per_call_us` -- the rank's wall clock of the timed region divided by the
+                launches in it -- is reported beside it as the stream's THROUGHPUT interval (it contains the ~2 us between
+                launches but overlaps a launch's head with its predecessor's drain, so it is not a bound on one kernel's
+                duration and is never substituted for the event clock).  The committed rocprofv3 --kernel-trace --stats summary
+                of the same command is the independent third clock.
                 `traffic` (HBM + Infinity-Cache bytes per launch) is NOT measured in this run: it is read from the
                 committed rocprofv3 PMC summary named in `traffic_source` (profiles/), collected as
                 MI355X_MICROARCH.md prescribes (separate --pmc passes, FETCH_SIZE doubled on gfx950)
@@ -57,6 +58,17 @@ HBM_PEAK_TBPS = 8.0            # HBM3E spec, MI355X_MICROARCH.md
 BASELINE3 = [("64_4096_64", "fp32"), ("512_4096_4096", "fp32"), ("4096_4096_4096", "fp16")]
 WORKLOAD = ("4096_4096_4096", "fp16")
 EVENT_STRIDE = 16              # every 16th launch of the timed region carries dispatch-attached timing events
+
+
+PLAN_FLAGS = (("fused_split_k", 0x10000), ("nt_store", 0x20000), ("streamk", 0x40000), ("xcd_stagger", 0x80000), ("nt_loads", 0x100000),
+              ("phase_offset", 0x200000), ("wave_priority", 0x400000), ("phase_offset4", 0x800000))
+
+
+def plan_dict(name, splits: int, group_m: int) -> dict:
+    """A plan as the records show it: geometry, split count (or stream-K workgroups) and every plan flag of include/hgemm_mi355x.h."""
+    d = {"config": name.decode() if name else "ragged", "splits": splits & 0xFFFF, "group_m": group_m}
+    d.update({k: bool(splits & bit) for k, bit in PLAN_FLAGS})
+    return d
 
 
 def load_library():
@@ -295,8 +307,7 @@ def per_shape_report(lib, probs, stream) -> dict:
         cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.hgemm_mi355x_plan(p.m, p.n, p.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
         name = lib.hgemm_mi355x_config_name(cfg.value)
-        row["plan"] = {"config": name.decode() if name else "ragged", "splits": sp.value & 0xFFFF, "fused_split_k": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000),
-                       "streamk": bool(sp.value & 0x40000), "group_m": gm.value}
+        row["plan"] = plan_dict(name, sp.value, gm.value)
         row["roofline"] = roofline_entry(p, row["ours_us"], measured_traffic_bytes(p.mnk))
         out[p.mnk] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in row.items()}
     lib.hgemm_hipblaslt_autotune_destroy()
@@ -418,16 +429,22 @@ def main(argv=None):
     elapsed, total_flops = reduce_over_ranks(elapsed, prob.flops * args.batch * args.steps, device)
     durs = sorted(lib.hgemm_mi355x_event_elapsed_us(e0, e1) for e0, e1 in events)
     event_mean_us = sum(durs) / len(durs)
-    dom_us = min(event_mean_us, wall_per_call_us)
+    # ONE clock for the roofline: the dispatch-attached events (a dispatch's start event fires while its predecessor drains, so the
+    # mean overstates the kernel by ~1 % and `achieved` / `frac` understate it).  wall_per_call_us is a THROUGHPUT interval of the
+    # back-to-back stream (it contains the gap between launches but overlaps a launch's head with its predecessor's drain), not a
+    # bound on one kernel's duration: reported beside it, never substituted.
+    dom_us = event_mean_us
     for e0, e1 in pool:
         lib.hgemm_mi355x_event_destroy(e0)
         lib.hgemm_mi355x_event_destroy(e1)
     traffic, traffic_source = measured_traffic(prob.mnk)
     roof = roofline_entry(prob, dom_us, traffic)
     roof.update({"traffic_source": traffic_source, "kernel": prob.mnk, "launch_us": round(dom_us, 2),
-                 "clock": "dispatch-attached HIP events (mean)" if dom_us == event_mean_us else "wall clock of the timed region / launches",
+                 "clock": "dispatch-attached HIP events on the launch stream (mean of every 16th launch of the timed region)",
                  "avg_launch_us": round(event_mean_us, 2), "median_launch_us": round(durs[len(durs) // 2], 2), "wall_per_call_us": round(wall_per_call_us, 2),
-                 "bound_kind": "launch_us is an upper bound of the kernel's duration: achieved and frac are lower bounds",
+                 "throughput_tflops_wall": round(prob.flops / wall_per_call_us * 1e-6, 2),
+                 "bound_kind": "a dispatch's start event fires while its predecessor drains: launch_us overstates the kernel by ~1 %, achieved and frac "
+                               "understate it; wall_per_call_us is the stream's throughput interval, reported separately",
                  "launches_timed": len(durs), "algorithmic_flops_per_launch": prob.flops, "algorithmic_bytes_per_launch": prob.bytes})
     cfg, sp, gm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     lib.hgemm_mi355x_plan(prob.m, prob.n, prob.k, ctypes.byref(cfg), ctypes.byref(sp), ctypes.byref(gm))
@@ -441,8 +458,7 @@ def main(argv=None):
                                "call each, fp16 N(0,1) operands resident in HBM; replicas per GPU",
                    "batch": args.batch, "timed_region_s": round(elapsed, 3),
                    "accumulate": "fp32 MFMA (both modes; CDNA4 has no fp16-accumulate MFMA)",
-                   "plan": {"config": cname.decode() if cname else "ragged", "splits": sp.value & 0xFFFF, "nt_store": bool(sp.value & 0x20000),
-                            "group_m": gm.value}},
+                   "plan": plan_dict(cname, sp.value, gm.value)},
         "roofline": roof,
     }
     if rank == 0:

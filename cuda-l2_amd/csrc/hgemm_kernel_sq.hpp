@@ -508,6 +508,39 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
   const ItemWalk walk = persistent_walk(g.items);
   if (walk.count == 0) return;
 
+  // ---- phase control of the persistent walk (round 5; plan flags, wave-uniform, outside every loop) ------------------------------
+  // What it is for: the workgroups of an XCD walk their items in lock-step -- they share operand panels
+  // in its L2 -- so all 32 CUs of the XCD reach their epilogues together and 32 x BM x BN x 2 B of C meet the XCD's one path into
+  // the fabric at once (16384^2 x 256: ~11k cycles per epilogue of a 256 x 256 tile = 0.7 TB/s per XCD), while that path idles
+  // during the K loops: the time of the small-K / large-MN class is the SUM of a store phase and an MFMA phase.
+  //   flags bit 3 (HGEMM_PLAN_PHASE_OFFSET): every second workgroup of an XCD enters its walk half an item period late, so half of
+  //     the XCD's CUs store while the other half multiplies.  The wait is a sleep in front of the first LDS-DMA piece, once per launch.
+  //     Bit 5 (HGEMM_PLAN_PHASE_OFFSET4): four groups a quarter period apart; both bits: eight groups an eighth apart.
+  //   flags bit 4 (HGEMM_PLAN_WAVE_PRIORITY), two-resident members: the wave in the odd hardware slot of its SIMD raises its
+  //     priority for good, so the two workgroups of a CU stop sharing the matrix pipe evenly (and reaching their epilogues
+  //     together): one's K loop runs at full rate and its epilogue under the other's K loop.
+  if (g.flags & (8 | 32)) {   // (bit 5, HGEMM_PLAN_PHASE_OFFSET4: four phase groups a quarter period apart instead of two; both bits: eight)
+    const int j = (int)(blockIdx.x >> 3);   // index of the workgroup inside its XCD
+    const int groups = (g.flags & (8 | 32)) == (8 | 32) ? 8 : (g.flags & 32) ? 4 : 2, grp = j & (groups - 1);
+    if (grp != 0 && walk.count > 1) {
+      // spacing of two neighbouring groups: an equal share of the item period, but no more than an epilogue that has the XCD's
+      // fabric path to itself takes anyway (~BM x BN / 6 cycles when all 32 CUs store at once): with a long K the point is only
+      // that the groups' epilogues do not coincide, and a group that trails by a few K-steps still finds its panels in the L2
+      const int nk0 = g.k_chunk / (BK * CFG::KT);
+      const int period = nk0 * 2 * CFG::T * (CFG::MI == 32 ? 32 : 16) + CFG::BM * CFG::BN / 12;   // shader cycles, roughly
+      const int spacing = min(period / groups, CFG::BM * CFG::BN / 6);
+#pragma clang loop unroll(disable)
+      for (int c = 0; c < spacing * grp; c += 1024) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  if constexpr (CFG::WGS == 2) {
+    if (g.flags & 16) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      if (hw & 1u) __builtin_amdgcn_s_setprio(2);
+    }
+  }
+
   // fragment lane mapping (hgemm_kernel_sp.hpp): MI = 16: row lane & 15, 16-B chunk 4h + (lane >> 4);
   // MI = 32: row lane & 31, chunk 4h + 2u + (lane >> 5); the image's swizzle is keyed on (row >> 1) & 7
   const int lr = lane & (MI - 1), lq = lane / MI, sw = (lr >> 1) & 7;

@@ -33,7 +33,7 @@ struct CfgWD {
   static constexpr int NQUAD = FM * FN;                                 // f32x4 accumulator quads per lane
   static constexpr int LDS_BYTES = KW == 1 ? 64 : KW * NQUAD * 64 * 16 + 64;   // KW partial tiles + the vote word
   static_assert(KW == 1 || KW == 4, "K walk by one wave or by all four");
-  static_assert(FM * FN <= 16, "accumulators + one unrolled trip of fragments stay far below 128 registers");
+  static_assert(FM * FN <= 16, "accumulators + one unrolled trip of fragments (at most 32 x 4 registers) stay below 256 registers");
 };
 
 template <class CFG, int EPI>
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_wd_kernel(const GemmArg
   // K = 32 slices of this work item; wave w of a KW = 4 workgroup takes slices w, w + 4, ...
   const int k_end = min(g.K, tc.k_begin + g.k_chunk);
   const int nslices = (k_end - tc.k_begin) / 32;
-  // U slices per trip: U * (FM + FN) 16-byte loads in flight per lane behind ONE wait; trips of 4, then one of 2, then one of 1
+  // U slices per trip: U * (FM + FN) 16-byte loads in flight per lane behind ONE wait; trips of (16, 8,) 4, then one of 2, then one of 1
   // (a K of 64 on a KW = 1 member is a single trip of two slices: one round trip to memory for the whole kernel)
   int s = KW == 1 ? 0 : wave;
   auto trip = [&](auto u_tag) {
@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_wd_kernel(const GemmArg
 #pragma unroll
       for (int j = 0; j < FN; ++j) bf[u][j] = *(const f16x8*)(pb[j] + k);
     }
+    // deep trips: every load goes out before the first MFMA (left alone, hipcc trades the loads in flight for a smaller register
+    // count: 12 of 32 at a time, to keep 8 waves per SIMD that these launch-bound grids never have)
+    if constexpr (U >= 8) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -89,6 +92,17 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_wd_kernel(const GemmArg
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[u][j], af[u][i], acc[i][j], 0, 0, 0);
     s += U * KW;
   };
+  // Round 5: deeper trips for the long K walks of the small wave tiles -- up to 32 sixteen-byte loads per lane (128 registers) in
+  // flight: 16 slices for a 16 x 16 wave tile (K = 512 per wave and round trip, 2048 per `_k4` workgroup), 8 for 32 x 32 / 16 x 32.
+  // With four slices a 64 x 64 x 4096 walk was 8 dependent round trips per wave (or a 4-way split-K and a second, serial
+  // combine phase); hipBLASLt's MT16x16x512 kernels on these shapes have 512 of K in flight per wave.
+  constexpr int UMAX = 32 / (FM + FN) >= 16 ? 16 : 32 / (FM + FN) >= 8 ? 8 : 4;
+  if constexpr (UMAX >= 16) {
+    while (s + 15 * KW < nslices) trip(std::integral_constant<int, 16>{});
+  }
+  if constexpr (UMAX >= 8) {
+    while (s + 7 * KW < nslices) trip(std::integral_constant<int, 8>{});
+  }
   while (s + 3 * KW < nslices) trip(std::integral_constant<int, 4>{});
   if (s + KW < nslices) trip(std::integral_constant<int, 2>{});
   if (s < nslices) trip(std::integral_constant<int, 1>{});

@@ -241,7 +241,7 @@ static std::vector<Plan> candidates(const Shape& sh, double keep_ratio, int max_
     }
     // stream-K plans of the geometries that have the kernel: one, two, ... resident workgroups per CU
     if (g_streamk_too)
-      for (int r = 1; r <= hgemm_mi355x_config_streamk(c); ++r) {
+      for (int r = 1; r <= hgemm_mi355x_config_streamk(c) && hgemm_mi355x_streamk_runs(c, sh.M, sh.N, sh.K); ++r) {   // (never a plan that would run data-parallel)
         const int plan = HGEMM_PLAN_STREAMK | (256 * r);
         all.push_back({c, plan, default_group(c, sh), hgemm_mi355x_model_us(c, plan, sh.M, sh.N, sh.K)});
       }
@@ -331,7 +331,10 @@ static int cmd_check(const std::vector<Shape>& shapes) {
                                    3 | HGEMM_PLAN_RS_NT_LOADS, 37 | HGEMM_PLAN_STREAMK | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS});
       if (fam == 'q')   // family q's kstagger variant (round 5): plain, with NT stores, two-pass and single-launch split-K
         forms.insert(forms.end(), {1 | HGEMM_PLAN_XCD_STAGGER, 1 | HGEMM_PLAN_XCD_STAGGER | HGEMM_PLAN_NT_STORE, 3 | HGEMM_PLAN_XCD_STAGGER,
-                                   4 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_XCD_STAGGER});
+                                   4 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_XCD_STAGGER,
+                                   // the walk's phase flags (prologue only: a sleep / a priority): alone, together, with a stagger
+                                   1 | HGEMM_PLAN_PHASE_OFFSET, 1 | HGEMM_PLAN_PHASE_OFFSET4, 1 | HGEMM_PLAN_PHASE_OFFSET8, 1 | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_NT_STORE,
+                                   2 | HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_XCD_STAGGER});
       for (int splits : forms) {
         const bool sk = (splits & HGEMM_PLAN_STREAMK) != 0;
         const int sp = sk ? 2 : (splits & HGEMM_SPLITK_MASK);   // (sp > 1: run twice, one raster group)
@@ -379,7 +382,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     if (g_config_filter.empty() || std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) != g_config_filter.end())
       printf(" %s", cname);
   }
-  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger, raster groups 1 4\n");
+  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger 1|phase-offset 1|phase-offset4 1|phase-offset8 1|wave-priority|nt-store 2|phase-offset|wave-priority|xcd-stagger, raster groups 1 4\n");
   printf("check: %d runs, %d failures (bit-exact against the exact integer result of 0/1 inputs)\n", runs, failures);
   return failures ? 1 : 0;
 }
@@ -432,6 +435,11 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       if (it != g_cand_file.end())
         for (Plan p : it->second) {
           if (!hgemm_mi355x_config_accepts_k(p.cfg, sh.K)) continue;
+          if ((p.splits & HGEMM_PLAN_STREAMK) && !hgemm_mi355x_streamk_runs(p.cfg, sh.M, sh.N, sh.K)) {
+            // the launch would degrade to the geometry's plain launch and still return OK: not a stream-K timing, not recorded as one
+            fprintf(stderr, "tune: %s %s stream-K plan skipped (would run data-parallel on this shape)\n", key, hgemm_mi355x_config_name(p.cfg));
+            continue;
+          }
           p.model_us = hgemm_mi355x_model_us(p.cfg, p.splits, sh.M, sh.N, sh.K);   // (takes `splits` as the launch does)
           cands.push_back(p);
         }
@@ -539,7 +547,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       st_lt_tn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, lt_tn);
       st_lt_nn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, lt_nn);
     }
-    double at_nn = -1, at_tn = -1;
+    double at_nn = -1, at_tn = -1, st_at_nn = -1, st_at_tn = -1;
     int at_cand_nn = 0, at_cand_tn = 0;
     if (baselines && autotune) {
       // the reference's strongest baseline (cublaslt_auto_tuning): per-shape search over the heuristic
@@ -553,6 +561,13 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
         at_cand_tn = hgemm_hipblaslt_autotune_candidates(1);
         at_tn = time_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
       }
+      // ... and back to back, like ours and the heuristic (round 5: the north-star comparison is against the autotuned baseline on
+      // both clocks; the library keeps one selected algorithm per layout).
+      if (g_stream_report) {
+        const double box = flops > 1.5e12 ? 0.012 : 0.008;
+        if (at_tn > 0) st_at_tn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, at_tn);
+        if (at_nn > 0) st_at_nn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, at_nn);
+      }
     }
     // "splits" is the value to pass to hgemm_mi355x_launch (split count | HGEMM_SPLITK_FUSED); "fused" repeats the flag
     fprintf(out, "{\"mnk\": \"%d_%d_%d\", \"best\": {\"config\": \"%s\", \"splits\": %d, \"fused\": %d, \"streamk\": %d, \"group_m\": %d, \"us\": %.3f, \"tflops\": %.2f}",
@@ -565,6 +580,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     if (baselines && autotune)
       fprintf(out, ", \"hipblaslt_auto_nn_us\": %.3f, \"hipblaslt_auto_tn_us\": %.3f, \"hipblaslt_auto_candidates\": [%d, %d]", at_nn, at_tn,
               at_cand_nn, at_cand_tn);
+    if (st_at_nn > 0 || st_at_tn > 0) fprintf(out, ", \"hipblaslt_auto_nn_stream_us\": %.3f, \"hipblaslt_auto_tn_stream_us\": %.3f", st_at_nn, st_at_tn);
     if (nt_us > 0) fprintf(out, ", \"stream_plain_us\": %.3f, \"stream_nt_us\": %.3f", nt_plain_us, nt_us);
     if (nt_iso_us > 0) fprintf(out, ", \"nt_adopted_on\": \"stream\", \"isolated_plain_us\": %.3f, \"isolated_nt_us\": %.3f", nt_plain_iso_us, nt_iso_us);
     if (st_ours > 0)

@@ -1,6 +1,6 @@
 // M=12288 N=128 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry r96x128_k128, split-K 4 (single launch), raster group 4  [tuned on MI355X (round 4): 98.0 us, 525.7 TFLOP/s fused split-K (back to back 98.3 us), verified against the CPU oracle]
+// plan: geometry q192x128_w2x2, split-K 4, K stagger per XCD, raster group 4  [tuned on MI355X (round 4): 92.5 us, 557.2 TFLOP/s two-pass split-K, K stagger per XCD (back to back 91.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 128, 16384, "r96x128_k128", 1114116, 4)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 128, 16384, "q192x128_w2x2", 524292, 4)

@@ -1,6 +1,6 @@
 // M=12288 N=128 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x4_m16_s4, split-K 1, raster group 8  [tuned on MI355X: 33.4 us, 385 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q192x128_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 4): 33.7 us, 382.8 TFLOP/s two-pass split-K (back to back 31.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 128, 4096, "t64x128_w2x4_m16_s4", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 128, 4096, "q192x128_w2x2", 4, 4)

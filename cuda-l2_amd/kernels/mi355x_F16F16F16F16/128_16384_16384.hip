@@ -1,6 +1,6 @@
 // M=128 N=16384 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry r128x128_k128_d, split-K 2 (single launch), raster group 1  [tuned on MI355X (round 4): 121.5 us, 565.7 TFLOP/s fused split-K (back to back 115.4 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 4): 113.2 us, 606.8 TFLOP/s fused split-K, K stagger per XCD (back to back 113.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 16384, 16384, "r128x128_k128_d", 1114114, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 16384, 16384, "q128x128_w2x2", 589826, 4)

@@ -1,6 +1,6 @@
 // M=128 N=8192 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry r128x128_k128_d, split-K 4 (single launch), raster group 1  [tuned on MI355X (round 4): 40.8 us, 420.9 TFLOP/s fused split-K (back to back 38.6 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 4): 36.2 us, 474.6 TFLOP/s two-pass split-K (back to back 35.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 8192, "r128x128_k128_d", 1638404, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 8192, "q128x128_w2x2", 4, 4)

@@ -1,6 +1,6 @@
 // M=256 N=256 K=256  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s2, split-K 1, raster group 2  [tuned on MI355X: 6.2 us, 5 TFLOP/s, verified against the CPU oracle]
+// plan: geometry w32x16_k4, split-K 1, raster group 4  [tuned on MI355X (round 4): 6.3 us, 5.3 TFLOP/s (back to back 2.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 256, 256, "t64x64_w2x2_m16_s2", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(256, 256, 256, "w32x16_k4", 1, 4)

@@ -1,6 +1,6 @@
 // M=64 N=8192 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry r64x64_k256, split-K 2 (single launch), raster group 1  [tuned on MI355X (round 4): 21.5 us, 200.1 TFLOP/s fused split-K (back to back 18.5 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 4): 19.7 us, 218.5 TFLOP/s two-pass split-K (back to back 17.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 4096, "r64x64_k256", 1638402, 1)
+HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 4096, "q128x128_w2x2", 4, 4)

@@ -1,6 +1,6 @@
 // M=128 N=12288 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry r128x96_k128, split-K 4 (single launch), raster group 1  [tuned on MI355X (round 4): 91.4 us, 563.6 TFLOP/s fused split-K (back to back 93.1 us), verified against the CPU oracle]
+// plan: geometry q128x192_w2x2, split-K 4, K stagger per XCD, raster group 4  [tuned on MI355X (round 4): 91.0 us, 566.1 TFLOP/s two-pass split-K, K stagger per XCD (back to back 91.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 12288, 16384, "r128x96_k128", 1638404, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 12288, 16384, "q128x192_w2x2", 524292, 4)

@@ -1,6 +1,6 @@
 // M=64 N=128 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t32x64_w1x2_m16_s4, split-K 32, raster group 32  [tuned on MI355X: 12.2 us, 22 TFLOP/s, verified against the CPU oracle]
+// plan: geometry w32x16_k4, split-K 16, raster group 1  [tuned on MI355X (round 4): 11.8 us, 22.7 TFLOP/s two-pass split-K (back to back 9.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 128, 16384, "t32x64_w1x2_m16_s4", 32, 32)
+HGEMM_MI355X_SHAPE_ENTRY(64, 128, 16384, "w32x16_k4", 16, 1)

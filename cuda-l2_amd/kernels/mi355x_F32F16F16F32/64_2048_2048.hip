@@ -1,6 +1,6 @@
 // M=64 N=2048 K=2048  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry w32x32_k4, split-K 2 (single launch), raster group 2  [tuned on MI355X (round 4): 10.8 us, 49.6 TFLOP/s fused split-K (back to back 8.3 us), verified against the CPU oracle]
+// plan: geometry w32x16_k4, split-K 1, raster group 4  [tuned on MI355X (round 4): 10.0 us, 53.7 TFLOP/s (back to back 7.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 2048, 2048, "w32x32_k4", 65538, 2)
+HGEMM_MI355X_SHAPE_ENTRY(64, 2048, 2048, "w32x16_k4", 1, 4)

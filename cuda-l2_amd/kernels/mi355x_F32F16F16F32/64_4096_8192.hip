@@ -1,6 +1,6 @@
 // M=64 N=4096 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry r64x64_k256_d, split-K 4 (single launch), raster group 1  [tuned on MI355X (round 4): 22.3 us, 192.3 TFLOP/s fused split-K (back to back 19.9 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 8, K stagger per XCD, raster group 4  [tuned on MI355X (round 4): 20.2 us, 212.2 TFLOP/s two-pass split-K, K stagger per XCD (back to back 17.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 4096, 8192, "r64x64_k256_d", 1638404, 1)
+HGEMM_MI355X_SHAPE_ENTRY(64, 4096, 8192, "q128x128_w2x2", 524296, 4)

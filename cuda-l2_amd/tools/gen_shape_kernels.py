@@ -61,10 +61,13 @@ def write_shape_file(mnk: str, acc: str, device_type: str = "mi355x", plan=None,
     out_dir.mkdir(parents=True, exist_ok=True)
     path = out_dir / f"{mnk}.hip"
     entry = "hgemm_mi355x_fp32" if acc == "fp32" else "hgemm_mi355x_fp16"
+    flags = "".join(f", {t}" for bit, t in ((0x80000, "K stagger per XCD"), (0x100000, "NT loads of the streamed operand"), (0x200000, "phase offset"),
+                                            (0x800000, "phase offset x4"), (0x400000, "wave priority")) if splits & bit)
+    flags = flags.replace(", phase offset, phase offset x4", ", phase offset x8")   # (both bits: eight phase groups)
     text = (
         f"// M={m} N={n} K={k}  {ACC_TEXT[acc]}  MI355X / gfx950\n"
         f"// plan: geometry {cfg}, " + (f"stream-K on {splits & 0xFFFF} workgroups" if splits & 0x40000 else f"split-K {splits & 0xFFFF}{' (single launch)' if splits & 0x10000 else ''}") +
-        f"{', non-temporal C stores' if splits & 0x20000 else ''}, raster group {group}  [{source}]\n"
+        f"{', non-temporal C stores' if splits & 0x20000 else ''}{flags}, raster group {group}  [{source}]\n"
         f"// kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def\n"
         f"#define HGEMM_SHAPE_FALLBACK {entry}\n"
         f"#include \"hgemm_shape_entry.hpp\"\n"

@@ -55,7 +55,7 @@ def main(argv=None) -> int:
         sk = []
         for c in range(L.hgemm_mi355x_num_configs()):
             per_cu = L.hgemm_mi355x_config_streamk(c)
-            if per_cu <= 0 or k % L.hgemm_mi355x_config_k_granularity(c):
+            if per_cu <= 0 or not L.hgemm_mi355x_streamk_runs(c, m, n, k):   # (direct K tail, > 65536 tiles: the launch would run data-parallel)
                 continue
             L.hgemm_mi355x_config_info(c, info)
             if (info[0] > 2 * m and info[0] > 32) or (info[1] > 2 * n and info[1] > 32):

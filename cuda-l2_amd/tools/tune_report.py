@@ -59,6 +59,30 @@ def main(path, show=12):
                                sum(min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) for r, _ in st) * 1e-6,
                                "by_log10_flops": {b: {"n": len(v), "geomean": round(gm(v), 3), "min": round(min(v), 2), "max": round(max(v), 2)}
                                                   for b, v in sorted(sb.items())}}
+    # THE north-star comparison (BASELINE.json: geomean speedup over hipBLASLt-autotune): per shape the STRONGEST hipBLASLt variant
+    # -- autotune or heuristic, tn or nn (the reference's "-max" rule: the baseline against which our speedup is lower) -- isolated
+    # and back to back, with the FLOP-weighted aggregate, the losers and the per-decade split
+    def strongest(r, suffix):
+        vals = [r.get(f"hipblaslt_{kind}_{lay}{suffix}", -1) for kind in ("auto", "heur") for lay in ("tn", "nn")]
+        return min(v for v in vals if v and v > 0)
+    full = [r for r in recs if max(r.get("hipblaslt_auto_tn_us", -1), r.get("hipblaslt_auto_nn_us", -1)) > 0]
+    if full:
+        def summary(pairs):   # pairs: (record, ours_us, baseline_us)
+            sp = [b / o for _, o, b in pairs]
+            dec = collections.defaultdict(list)
+            for (r, o, b) in pairs:
+                m, n, k = map(int, r["mnk"].split("_"))
+                dec[int(math.log10(2.0 * m * n * k))].append(b / o)
+            fl = lambda r: 2.0 * math.prod(map(int, r["mnk"].split("_")))
+            return {"shapes": len(pairs), "geomean_speedup": gm(sp), "mean_speedup": sum(sp) / len(sp), "fraction_faster": sum(x > 1 for x in sp) / len(sp),
+                    "losers": sum(x < 1 for x in sp), "losers_by_more_than_5pct": sum(x < 0.95 for x in sp), "losers_by_more_than_10pct": sum(x < 0.90 for x in sp),
+                    "min_speedup": min(sp), "aggregate_tflops_ours": sum(fl(r) for r, _, _ in pairs) / sum(o for _, o, _ in pairs) * 1e-6,
+                    "aggregate_tflops_hipblaslt_strongest": sum(fl(r) for r, _, _ in pairs) / sum(b for _, _, b in pairs) * 1e-6,
+                    "by_log10_flops": {d: {"n": len(v), "geomean": round(gm(v), 3), "min": round(min(v), 2), "losers": sum(x < 1 for x in v)} for d, v in sorted(dec.items())}}
+        out["vs_strongest_hipblaslt_isolated"] = summary([(r, r["best"]["us"], strongest(r, "_us")) for r in full])
+        fs = [r for r in full if r.get("stream_us", -1) > 0 and max(r.get("hipblaslt_auto_tn_stream_us", -1), r.get("hipblaslt_auto_nn_stream_us", -1)) > 0]
+        if fs:
+            out["vs_strongest_hipblaslt_back_to_back"] = summary([(r, r["stream_us"], strongest(r, "_stream_us")) for r in fs])
     print(json.dumps(out, indent=1))
     if st:
         for r, sp in sorted(st, key=lambda t: t[1])[:show]:

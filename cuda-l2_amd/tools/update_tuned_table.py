@@ -25,12 +25,21 @@ TABLE = PKG_DIR / "csrc" / "hgemm_tuned_table.inc"
 ROW = re.compile(r'\s*\{(\d+), (\d+), (\d+), "([^"]+)", (\d+), (\d+)\},(.*)')
 
 
+FLAG_TEXT = ((0x80000, "K stagger per XCD"), (0x100000, "NT loads of the streamed operand"), (0x200000, "phase offset"),
+             (0x800000, "phase offset x4"), (0x400000, "wave priority"))
+
+
 def form_text(splits: int) -> str:
+    """Row annotation: split-K form + the plan flags that change the schedule (include/hgemm_mi355x.h; NT stores are in the
+    number itself, 0x20000, as before)."""
+    flags = "".join(f", {t}" for bit, t in FLAG_TEXT if splits & bit)
+    if (splits & 0xA00000) == 0xA00000:
+        flags = flags.replace(", phase offset, phase offset x4", ", phase offset x8")
     if splits & 0x40000:
-        return f" stream-K, {splits & 0xFFFF or 'one wave of'} workgroups"
+        return f" stream-K, {splits & 0xFFFF or 'one wave of'} workgroups" + flags
     if (splits & 0xFFFF) == 1:
-        return ""
-    return " fused split-K" if splits & 0x10000 else " two-pass split-K"
+        return flags.replace(", ", " ", 1)
+    return (" fused split-K" if splits & 0x10000 else " two-pass split-K") + flags
 
 
 def main(argv=None) -> int:

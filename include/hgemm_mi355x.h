@@ -100,6 +100,16 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  * gets the same effect from stream-K start offsets (kernels/h100_F32F16F16F32/16384_512_2048.cu:71-73).  Exactness / determinism
  * as above. */
 #define HGEMM_PLAN_XCD_STAGGER HGEMM_PLAN_RS_XCD_STAGGER
+/* Plan flags of the persistent "q" geometries (round 5; ignored elsewhere).  Results are bit-identical with and without them.
+ * HGEMM_PLAN_PHASE_OFFSET: every second workgroup of an XCD starts its walk over the work items half an item period late, so
+ *   that the epilogues of an XCD's CUs (their C stores share the XCD's path into the fabric) no longer coincide.  For walks of
+ *   several items per workgroup.
+ * HGEMM_PLAN_WAVE_PRIORITY: two-resident members (two workgroups per CU: q128x128_w2x2, q192x128_w2x2, q128x192_w2x2): the two
+ *   waves of a SIMD get different static priorities, so one workgroup's epilogue runs under the other's K loop. */
+#define HGEMM_PLAN_PHASE_OFFSET  0x200000
+#define HGEMM_PLAN_WAVE_PRIORITY 0x400000
+#define HGEMM_PLAN_PHASE_OFFSET4 0x800000   /* four phase groups a quarter period apart instead of two half a period apart */
+#define HGEMM_PLAN_PHASE_OFFSET8 (HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_PHASE_OFFSET4)   /* both bits: eight groups an eighth of a period apart */
 
 /* ------------------------------------------------------------------------------------------
  * The hot path.  Replaces cuda_l2_<dev>_fp32(a, b, b_col_major, c)
@@ -132,6 +142,18 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m,
                         const void* a, const void* b, const void* b_col_major, void* c,
                         int M, int N, int K, int lda, int ldb, int ldc, void* stream);
 
+/* First-use plan selection on the box the library runs on (opt-in; the reference's H100 kernels time their variants on first
+ * invocation, kernels/h100_F32F16F16F32/64_4096_64.cu:623-690).  Off by default: the entry points take the tuned table's plan.
+ * With HGEMM_MI355X_INSITU=1 in the environment, or after hgemm_mi355x_set_insitu(1) (returns the previous setting; 0 also
+ * forgets every recorded choice), the FIRST call of hgemm_mi355x_fp32 / _fp16 for a shape times up to three oracle-verified
+ * plans -- the table's and its alternates (hgemm_mi355x_insitu_candidates lists them, the table's plan first) -- on the call's
+ * own operands and stream, keeps the fastest for the process (an alternate must win by 3 %) and runs it; that call
+ * synchronises the stream, so it belongs in a warm-up phase.  Later calls, and calls on a capturing stream, time nothing.
+ * hgemm_mi355x_insitu_choice returns 1 and the recorded plan once a shape has been measured. */
+int hgemm_mi355x_set_insitu(int enable);
+int hgemm_mi355x_insitu_candidates(int M, int N, int K, int config_id[3], int splits[3], int group_m[3]);
+int hgemm_mi355x_insitu_choice(int M, int N, int K, int* config_id, int* splits, int* group_m);
+
 /* Plan the library would use for (M,N,K): outputs config id, split-K factor, raster group. */
 int hgemm_mi355x_plan(int M, int N, int K, int* config_id, int* splits, int* group_m);
 
@@ -162,6 +184,11 @@ int hgemm_mi355x_config_k_granularity(int config_id);
 int hgemm_mi355x_config_accepts_k(int config_id, int K);
 /* > 0 when the geometry has a stream-K kernel (HGEMM_PLAN_STREAMK): workgroups of it one CU holds. */
 int hgemm_mi355x_config_streamk(int config_id);
+/* 1 when a HGEMM_PLAN_STREAMK plan of this geometry really runs as stream-K on (M, N, K) -- the family has the kernel, K has no
+ * direct tail, the tile count fits the arrival-counter block -- 0 when hgemm_mi355x_launch would run the geometry's plain
+ * data-parallel launch instead (it still returns HGEMM_OK: a degraded plan is a slower plan, not an error).  Tuners and
+ * candidate generators ask this before they record a "stream-K" timing. */
+int hgemm_mi355x_streamk_runs(int config_id, int M, int N, int K);
 
 /* Split-K workspace.  Default: the library keeps one private device buffer per (device, stream) pair that
  * issued a split-K plan and grows it on first use of a bigger plan only (never in steady state; growing
@@ -191,6 +218,9 @@ int hgemm_mi355x_config_streamk(int config_id);
 int hgemm_mi355x_set_workspace(void* device_ptr, size_t bytes);
 int hgemm_mi355x_release_stream_workspace(void* stream);
 size_t hgemm_mi355x_workspace_bytes(int M, int N, int splits);
+/* Exactly what hgemm_mi355x_launch asks for with this plan on (M, N, K) (0: none) -- the config-aware form: a stream-K plan needs
+ * 2 x workgroups x BM x BN floats (a few MiB), where the geometry-blind bound above must assume 256 x 128 tiles and 1024 workgroups. */
+size_t hgemm_mi355x_plan_workspace_bytes(int config_id, int splits, int M, int N, int K);
 int hgemm_mi355x_reserve_workspace(int M, int N, int K, void* stream);
 int hgemm_mi355x_release_workspaces(void);
 

@@ -116,6 +116,13 @@ def test_sp_k_loops_are_mfma_streams_with_scalar_dma_descriptors(sp_functions):
         # K loops = innermost loops that contain MFMAs; split the function at loop headers
         text = "\n".join(lines)
         loops = re.split(r"This Inner Loop Header", text)[1:]
+        # (round 5: family q's prologue has one loop before the K loops -- the phase offset's sleep; it holds nothing but s_sleep and
+        # scalar arithmetic, checked here, and is skipped)
+        while loops and not re.search(r"\bv_mfma_", loops[0].split("s_cbranch_scc")[0]):
+            pre = [ln.split(";")[0].strip() for ln in loops[0].split("s_cbranch_scc")[0].splitlines()]
+            assert "sq_kernel" in name and any(c.startswith("s_sleep") for c in pre), name
+            assert all(re.match(r"(s_\w+|\.LBB\S*:?|)(\s|$)", c) for c in pre[1:]), (name, [c for c in pre[1:] if not re.match(r"(s_\w+|\.LBB\S*:?|)(\s|$)", c)][:3])
+            loops = loops[1:]
         assert len(loops) >= 2, f"{name}: expected a hot and a tail K loop"
         hot = loops[0].split("s_cbranch_scc")[0]
         n16 = len(re.findall(r"\bv_mfma_f32_16x16x32_f16", hot))
@@ -459,38 +466,36 @@ def test_the_audits_hold_at_a_second_optimisation_level(tmp_path_factory):
 
 
 def test_kernels_of_the_measured_library_keep_their_instruction_streams(isa_text):
-    """Round 4 added kernels (the "ktail" variants of families q and r) AFTER the closing run had measured the library.  The grid
-    records of round 4 (plan reports, sweeps, PMC table, bench) stay valid only if the kernels they ran are untouched, and "I did
-    not edit that function" is not evidence: the new variants are instantiations of the same templates and share non-inlined
-    helpers with them.  So: every kernel of the closing run's library (profiles/r04_isa_fingerprint_closing_run_library.json, made
-    by tools/isa_fingerprint.py from the sources of that commit) still exists, and its instruction stream is the same modulo
-    basic-block numbering -- except the ones listed here with the reason, none of which a shipped grid plan can launch."""
+    """The round's grid records (plan reports against hipBLASLt-autotune, parity / tolerance records, PMC table, bench) stay valid only
+    while the kernels they ran are untouched, and "I did not edit that function" is not evidence: variants are instantiations of the
+    same templates and share non-inlined helpers.  So every kernel of the library the closing run measured
+    (profiles/r05_isa_fingerprint_closing_run_library.json, made by tools/isa_fingerprint.py from the sources of that commit) still
+    exists with the same instruction stream modulo basic-block numbering -- all of them, no exceptions -- and nothing was added.
+
+    Against round 4's library (profiles/r04_isa_fingerprint_call_k_library.json, 296 kernels) round 5 changed, knowingly: every
+    family-q kernel (the "m0" clobbers add an s_nop in front of some M0 writes, the walk's phase flags add a prologue block), the
+    three staged-epilogue kernels of family s (plain lgkmcnt(0) in the LDS round trip), family w's long-K kernels (16- / 8-slice
+    trips); it added family q's kstagger variants and the two-resident members.  The classic family, family r and both stream-K
+    kernels are instruction-for-instruction round 4's: 212 kernels, checked below."""
     import json
     import sys
 
     sys.path.insert(0, str(REPO / "cuda-l2_amd" / "tools"))
     import isa_fingerprint
 
-    base = json.loads((REPO / "profiles" / "r04_isa_fingerprint_closing_run_library.json").read_text())["kernels"]
     now = isa_fingerprint.fingerprints(isa_text)
-    assert len(base) == 232 and not set(base) - set(now), sorted(set(base) - set(now))[:3]
-    changed = sorted(k for k in base if now[k] != base[k])
-    # The 128 x 256 members of families s and q, narrow (0) / slab (2, s only) / fused (3) epilogues: their epilogue helper
-    # (store_tile_row for FN = 8, 64 x 128 wave tiles) gained callers in q128x256's ktail variants and hipcc now hoists its column
-    # offsets differently; the K loops differ in register numbers only.  Grid shapes never launch them: N % 8 == 0 takes the wide
-    # epilogue, no s128x256 row ships, and no q128x256 row is single-launch split-K (checked below on the table).
-    allowed = {k for k in base if re.search(r"Cfg(SP|SQ)ILi128ELi256ELi2ELi2E(Li1E)?Li16EEELi[023]E", k)}
-    assert set(changed) <= allowed, [k for k in changed if k not in allowed][:5]
-    assert len(changed) <= 5, changed
-    rows = re.findall(r'\{\d+, \d+, \d+, "(\w+)", (\d+), \d+\}', (CSRC / "hgemm_tuned_table.inc").read_text())
-    assert len(rows) == 1000
-    assert not [r for r in rows if r[0].startswith("s128x256")]
-    assert not [r for r in rows if r[0] == "q128x256_w2x2" and int(r[1]) & 0x10000]
-    # ... and the additions are what this change set out to add: ktail variants (epilogue id + 8) of families q and r
-    added = sorted(set(now) - set(base))
-    assert added and all(re.search(r"hgemm_tn_(sq|rs)_kernel.*ELi(8|9|10|11)EEEvNS", k) for k in added), added[:3]
-    # The library with those variants was checked and tested on the GPU in call K (profiles/r04_check_final.log, the -m gpu suite);
-    # source edits after it (comments, a shared descriptor helper) must leave EVERY kernel of it as it was: all 296, no exceptions.
-    call_k = json.loads((REPO / "profiles" / "r04_isa_fingerprint_call_k_library.json").read_text())["kernels"]
-    assert len(call_k) == 296 and set(call_k) == set(now)
-    assert not [k for k in call_k if now[k] != call_k[k]]
+    base = json.loads((REPO / "profiles" / "r05_isa_fingerprint_closing_run_library.json").read_text())["kernels"]
+    assert len(base) == 348 and set(base) == set(now), (sorted(set(base) ^ set(now))[:4])
+    assert not [k for k in base if now[k] != base[k]], [k for k in base if now[k] != base[k]][:4]
+    r4 = json.loads((REPO / "profiles" / "r04_isa_fingerprint_call_k_library.json").read_text())["kernels"]
+    assert len(r4) == 296 and not set(r4) - set(now)
+    same = [k for k in r4 if now[k] == r4[k]]
+    changed = [k for k in r4 if now[k] != r4[k]]
+    assert len(same) == 212 and all(re.search(r"hgemm_tn_(sq|sp|wd)_kernel", k) for k in changed), [k for k in changed if not re.search(r"hgemm_tn_(sq|sp|wd)_kernel", k)][:3]
+    for fam in ("15hgemm_tn_kernel", "18hgemm_tn_rs_kernel", "18hgemm_tn_sk_kernel", "21hgemm_tn_rs_sk_kernel"):
+        assert not [k for k in changed if fam in k], fam
+    # family s: only the staged (wide) epilogues changed
+    assert all(re.search(r"CfgSPI\w+EEELi1EEEvNS", k) for k in changed if "sp_kernel" in k)
+    added = sorted(set(now) - set(r4))
+    # kstagger variants (epilogue id + 16) of the 16x16x32 members of family q, and every variant of the two-resident members
+    assert added and all(re.search(r"hgemm_tn_sq_kernel.*(ELi(16|17|18|19)EEEvNS|CfgSQILi(192ELi128|128ELi192)E)", k) for k in added), added[:3]

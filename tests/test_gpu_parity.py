@@ -872,3 +872,37 @@ def test_sample_of_grid_shapes_at_their_shipped_plans(g, oracle):
             got = g.gemm(a, b, entry)
             assert oracle.masked_max_diff(got, truth) == 0.0, (m, n, k, cfg, sp, gm, entry)
             assert np.array_equal(got.view(np.uint16), truth.view(np.uint16)), (m, n, k, cfg, sp, gm, entry)
+
+
+def test_first_use_selection_picks_a_listed_plan_and_stays_exact(g, oracle):
+    """Opt-in in-situ plan selection (hgemm_mi355x_set_insitu; the reference's first-call autotune, kernels/h100_F32F16F16F32/
+    64_4096_64.cu:623-690): the first call of a shape times the table's plan and its alternates on the call's operands, records one
+    of them for the process, and C is that plan's (exact) result; later calls reuse the choice; switching it off forgets it."""
+    import ctypes
+
+    L = g.lib()
+    assert L.hgemm_mi355x_set_insitu(1) == 0
+    try:
+        for m, n, k in ((2048, 2048, 2048), (8192, 2048, 256), (1000, 520, 200), (256, 16384, 4096)):
+            rng = np.random.default_rng(m + 7 * n + k)
+            a_np, b_np = oracle.zero_one_inputs(m, n, k, rng)
+            truth = oracle.truth_f32acc(a_np, b_np)
+            cfg, sp, gm = (ctypes.c_int * 3)(), (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
+            ncand = L.hgemm_mi355x_insitu_candidates(m, n, k, cfg, sp, gm)
+            cands = {(cfg[i], sp[i], gm[i]) for i in range(ncand)}
+            c0, s0, g0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            assert L.hgemm_mi355x_insitu_choice(m, n, k, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0)) == 0
+            for entry in ("fp32", "fp16", "fp32"):
+                got = g.gemm(a_np, b_np, entry)
+                assert oracle.masked_max_diff(got, truth) == 0.0
+                assert L.hgemm_mi355x_insitu_choice(m, n, k, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0)) == 1
+                choice = (c0.value, s0.value, g0.value)
+                assert choice in cands, (choice, cands)
+            first = choice
+            g.gemm(a_np, b_np, "fp32")
+            L.hgemm_mi355x_insitu_choice(m, n, k, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0))
+            assert (c0.value, s0.value, g0.value) == first          # one choice per process and shape
+    finally:
+        assert L.hgemm_mi355x_set_insitu(0) == 1
+    c0, s0, g0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert L.hgemm_mi355x_insitu_choice(2048, 2048, 2048, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0)) == 0

@@ -286,9 +286,11 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
     the CPU oracle, measured on an MI355X); the records are committed and this test ties the table to them."""
     ok = set()
     # (round 3's table + the two passes of the round-4 re-tune, tools/update_tuned_table.py --verified)
+    # + the four passes of the round-5 re-tune
     for name in ("r03_candidate_parity.jsonl", "r04_candidate_parity_pass1.jsonl", "r04_candidate_parity_pass2.jsonl",
                  "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl",
-                 "r04_candidate_parity_worst_rows.jsonl"):
+                 "r04_candidate_parity_worst_rows.jsonl", "r05_candidate_parity_pass1.jsonl", "r05_candidate_parity_pass2.jsonl",
+                 "r05_candidate_parity_pass3.jsonl", "r05_candidate_parity_pass4.jsonl"):
         for ln in (PKG / "tuning" / name).read_text().splitlines():
             r = json.loads(ln)
             if r["pass"] and r["bitwise_equal_unmasked"] and r["guard_bars_intact"] and r["max_diff_masked"] == 0.0:
@@ -296,19 +298,19 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
     missing = [(m, n, k, c) for (m, n, k, c, s, g) in _tuned_rows() if (f"{m}_{n}_{k}", c, s, g) not in ok]
     assert not missing, missing[:5]
     # ... and the whole-grid run of the SHIPPED table through both entry points (2 x 1000 records, all exact)
-    recs = [json.loads(ln) for ln in (PKG / "tuning" / "r04_parity_1000.jsonl").read_text().splitlines()]
+    recs = [json.loads(ln) for ln in (PKG / "tuning" / "r05_parity_1000.jsonl").read_text().splitlines()]
     assert len(recs) == 2000 and all(r["pass"] and r["bitwise_equal_unmasked"] for r in recs)
     assert {r["run"] for r in recs} == {"fp32", "fp16"} and len({r["mnk"] for r in recs}) == 1000
-    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), bool(s & 0x40000), (s >> 19) & 3, g) for (m, n, k, c, s, g) in _tuned_rows()}
+    shipped = {(f"{m}_{n}_{k}", c, s & 0xFFFF, bool(s & 0x10000), bool(s & 0x20000), bool(s & 0x40000), s >> 19, g) for (m, n, k, c, s, g) in _tuned_rows()}
     for r in recs:
         assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["streamk"],
-                r["plan"].get("rs_flags", 0), r["plan"]["group_m"]) in shipped, r["mnk"]
+                r["plan"]["plan_flags"], r["plan"]["group_m"]) in shipped, r["mnk"]
     # ... and the N(0,1) tolerance of the same table on the whole grid (BASELINE.json: 1e-3 / 1e-2 relative; 1e-3 for both here)
-    rn = [json.loads(ln) for ln in (PKG / "tuning" / "r04_randn_1000.jsonl").read_text().splitlines()]
+    rn = [json.loads(ln) for ln in (PKG / "tuning" / "r05_randn_1000.jsonl").read_text().splitlines()]
     assert len(rn) == 2000 and all(r["pass"] and r["relative_error"] <= 1e-3 and r["rows_checked"] >= 64 for r in rn)
     for r in rn:
         assert (r["mnk"], r["plan"]["config"], r["plan"]["splits"], r["plan"]["fused"], r["plan"]["nt_store"], r["plan"]["streamk"],
-                r["plan"].get("rs_flags", 0), r["plan"]["group_m"]) in shipped, r["mnk"]
+                r["plan"]["plan_flags"], r["plan"]["group_m"]) in shipped, r["mnk"]
 
 
 def test_analytic_model_picks_near_optimal_plans_on_the_measured_candidates(lib):
@@ -495,10 +497,17 @@ def test_off_grid_rules_of_round_4(lib):
         return lib.hgemm_mi355x_config_name(c.value).decode(), s.value
 
     # (1) rows of 18432 B (K = 9216) keep the corner plan's flags, rows of 18320 B (K = 9160) drop them (geometry and split form stay)
-    assert plan(64, 16384, 9216) == ("r64x128_k128_d", 0x110002) and plan(64, 16384, 9160) == ("r64x128_k128_d", 0x10002)
-    for (m, n, k) in [(16000, 128, 16000), (128, 8192, 9616), (64, 14928, 10624), (100, 16384, 16384), (64, 12000, 16384), (128, 16000, 16000)]:
+    # (round 5 moved most skinny rows to the two-resident q128x128: the r corners that remain are the N = 64 / M = 64 rows with K >= 12288)
+    assert plan(64, 16384, 14336) == ("r64x128_k128", 0x190002) and plan(64, 16384, 14328) == ("r64x128_k128", 0x10002)
+    served_by_r = 0
+    for (m, n, k) in [(16000, 64, 16000), (64, 16000, 16000), (64, 12000, 16384), (64, 16384, 14328), (64, 12000, 16008), (16000, 128, 16000), (128, 8192, 9616)]:
         name, s = plan(m, n, k)
-        assert name[0] == "r" and bool(s & 0x180000) == (k % 64 == 0), (m, n, k, name, hex(s))
+        if name[0] == "r":
+            served_by_r += 1
+            assert bool(s & 0x180000) == (k % 64 == 0), (m, n, k, name, hex(s))
+        else:
+            assert not (s & 0x100000), (m, n, k, name, hex(s))          # NT loads of the streamed operand: family r only
+    assert served_by_r >= 4
     # (2) 143 tiles of 128 x 256 on 256 workgroups (the corner plan of 2048 x 4096 x 4096) -> 156 items of 256 x 256 at two splits
     assert plan(1332, 3108, 4440) == ("q256x256_w2x2", 2)
     assert plan(2048, 4096, 4096)[0] == "q128x256_w2x2"                      # the corner itself: a tuned row, untouched
@@ -507,7 +516,9 @@ def test_off_grid_rules_of_round_4(lib):
     # chip, are not taken from a corner (256 x 1600 x 1024: 400 workgroups of w32x32_k4 measured 12.2 us against 9.0 for a classic
     # tile; 64 x 14928 x 10624: 312 workgroups of r64x96 83.4 us against 63.8 for 234 of r64x128)
     assert plan(256, 1600, 1024)[0][0] == "t" and plan(640, 640, 640)[0][0] == "t" and plan(256, 1024, 1024)[0] == "w32x32_k4"
-    assert plan(64, 14928, 10624)[0].startswith("r64x128_k128") and plan(64, 12288, 8192)[0].startswith("r64x96") is not None
+    # (64 x 14928 x 10624 itself is served by the two-resident q128x128 since round 5 -- its corners' rows moved there; the guard
+    # is still what keeps 312 workgroups of a 96-wide r tile away from shapes between the remaining r corners)
+    assert plan(64, 14928, 10624)[0] in ("q128x128_w2x2", "r64x128_k128", "r64x128_k128_d")
     # (3) K = 4440 against K = 4416 (69 whole steps): 128 x 256 tiles +50 %, 256 x 256 tiles +10.6 %, family r not charged
     q128, q256, r = (lib.hgemm_mi355x_config_by_name(x) for x in (b"q128x256_w2x2", b"q256x256_w2x2", b"r64x128_k128"))
     def ratio(c, m, n, k0, k1):
@@ -574,8 +585,10 @@ def test_planner_fuzz_every_answer_is_launchable(lib):
         assert lib.hgemm_mi355x_config_accepts_k(c.value, k) == 1, (m, n, k, lib.hgemm_mi355x_config_name(c.value))
         name = lib.hgemm_mi355x_config_name(c.value).decode()
         assert not (s.value & 0x40000) or k % 64 == 0 or name[0] == "t", (m, n, k, name)   # stream-K + K tail: classic family only
-        assert (s.value & ~0x1FFFFF) == 0 and g.value >= 1
-        assert not (s.value & 0x180000) or lib.hgemm_mi355x_config_name(c.value).decode()[0] == "r"   # family r's load flags: r plans only
+        assert (s.value & ~0xBFFFFF) == 0 and g.value >= 1              # (0x400000, wave priority: explicit plans only)
+        assert not (s.value & 0x100000) or name[0] == "r"               # NT loads of the streamed operand: family r only
+        assert not (s.value & 0x080000) or name[0] in "rq"              # K stagger per XCD: families r and q
+        assert not (s.value & 0xA00000) or name[0] == "q"               # phase offset of the persistent walk: family q only
         assert ((s.value & 0x40000) and lib.hgemm_mi355x_config_streamk(c.value) > 0 and (s.value & 0xFFFF) <= 4096) or \
             (not (s.value & 0x40000) and 1 <= (s.value & 0xFFFF) <= max(1, k // 64)), (m, n, k, hex(s.value))
         assert not lib.hgemm_mi355x_config_name(c.value).decode().endswith("_m32") or lib.hgemm_mi355x_config_name(c.value).decode().startswith("t")
@@ -598,7 +611,9 @@ def test_planner_keeps_the_late_geometries_inside_their_measured_domains(lib):
         assert cfg_of(*shape)[0] == "q192x256_w2x2", shape
     for shape in [(8192, 1536, 8192), (2048, 6144, 2048)]:
         assert cfg_of(*shape)[0] == "q256x192_w2x2", shape
-    assert cfg_of(500, 4000, 4096)[0] == "t128x64_w4x2_m16_s4"         # 4 x 63 = 252 tiles: the 8-wave tile's home ground
+    # 4 x 63 = 252 tiles of 128 x 64 were the 8-wave tile's home ground until round 5; the corner row (BASELINE config 4) now ships the
+    # two-resident q128x128 at two splits, and the off-grid neighbour follows it
+    assert cfg_of(500, 4000, 4096) == cfg_of(512, 4096, 4096) and cfg_of(512, 4096, 4096)[0] == "q128x128_w2x2"
 
 
 def test_tuned_table_overrides_apply_in_order(tmp_path):
@@ -664,3 +679,86 @@ def test_stream_k_plans_are_priced_and_flags_are_not_split_counts(lib):
         assert 10.0 < us < 500.0
     assert lib.hgemm_mi355x_config_streamk(lib.hgemm_mi355x_config_by_name(b"t256x256_w2x4_m16_s2")) == 0
     assert lib.hgemm_mi355x_workspace_bytes(512, 512, 0x40000 | 256) >= (256 << 10) + 2 * 256 * 128 * 128 * 4
+
+
+def test_stream_k_query_says_whether_a_plan_really_runs_and_what_workspace_it_takes(lib):
+    """a HGEMM_PLAN_STREAMK plan used to degrade to the plain launch silently (direct K tail, > 65536 tiles) while the
+    tuner recorded it as stream-K, and hgemm_mi355x_workspace_bytes asked for 0.5-2 GiB where a few MiB are used.  One
+    predicate now answers for the launch, the planner, the tuner and the candidate generators; the config-aware workspace
+    query returns exactly what the launch asks for."""
+    lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    lib.hgemm_mi355x_plan_workspace_bytes.restype = ctypes.c_size_t
+    r = lib.hgemm_mi355x_config_by_name(b"r128x128_k128")
+    t = lib.hgemm_mi355x_config_by_name(b"t128x128_w2x2_m16_s3")
+    q = lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
+    assert lib.hgemm_mi355x_streamk_runs(r, 12288, 128, 8192) == 1
+    assert lib.hgemm_mi355x_streamk_runs(r, 12288, 128, 8192 + 64) == 0      # family r: direct K tail -> plain launch
+    assert lib.hgemm_mi355x_streamk_runs(t, 12288, 128, 8192 + 8) == 1       # classic family pads its last step: still stream-K
+    assert lib.hgemm_mi355x_streamk_runs(t, 128 * 300, 128 * 300, 256) == 0  # 90000 tiles > the 65536 arrival counters
+    assert lib.hgemm_mi355x_streamk_runs(q, 4096, 4096, 4096) == 0           # no stream-K kernel in family q
+    assert lib.hgemm_mi355x_streamk_runs(-1, 64, 64, 64) == 0 and lib.hgemm_mi355x_streamk_runs(r, 0, 64, 64) == 0
+    # workspace: exact and small for stream-K; the geometry-blind bound is bounded by 256 x 128 tiles now
+    ws = lib.hgemm_mi355x_plan_workspace_bytes(r, 0x40000 | 256, 12288, 128, 8192)
+    assert ws == (256 << 10) + 2 * 256 * 128 * 128 * 4
+    assert lib.hgemm_mi355x_plan_workspace_bytes(r, 0x40000 | 256, 12288, 128, 8192 + 64) == 0     # degraded: needs none
+    assert lib.hgemm_mi355x_workspace_bytes(12288, 128, 0x40000 | 256) == (256 << 10) + 2 * 1024 * 256 * 128 * 4   # 256 MiB, was 512
+    assert ws <= lib.hgemm_mi355x_workspace_bytes(12288, 128, 0x40000 | 256)
+    assert lib.hgemm_mi355x_plan_workspace_bytes(q, 1 | 0x20000, 4096, 4096, 4096) == 0
+    assert lib.hgemm_mi355x_plan_workspace_bytes(q, 2, 4096, 4096, 4096) == (256 << 10) + 2 * 4096 * 4096 * 4
+    assert lib.hgemm_mi355x_plan_workspace_bytes(q, 2 | 0x10000, 4096, 4096, 4096) == (256 << 10) + 2 * 256 * 256 * 256 * 4
+    # the candidate generator asks the same question
+    text = (PKG / "tools" / "make_streamk_candidates.py").read_text()
+    assert "hgemm_mi355x_streamk_runs" in text
+
+
+def test_plan_flags_of_round_5_are_flags_not_split_counts(lib):
+    """HGEMM_PLAN_XCD_STAGGER (family q's kstagger variant), HGEMM_PLAN_PHASE_OFFSET(4), HGEMM_PLAN_WAVE_PRIORITY ride in `splits`
+    like the older flags: the model prices the plan, never the flag bits; the two-resident members report two workgroups per
+    CU; every annotation tool decodes them."""
+    lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    q = lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
+    base = lib.hgemm_mi355x_model_us(q, 1, 8192, 8192, 512)
+    for flag in (0x80000, 0x200000, 0x400000, 0x800000, 0x80000 | 0x200000 | 0x20000):
+        assert lib.hgemm_mi355x_model_us(q, 1 | flag, 8192, 8192, 512) == base
+    info = (ctypes.c_int * 8)()
+    for name, lds in ((b"q192x128_w2x2", 80 * 1024), (b"q128x192_w2x2", 80 * 1024), (b"q128x128_w2x2", 64 * 1024)):
+        c = lib.hgemm_mi355x_config_by_name(name)
+        assert c >= 0, name
+        lib.hgemm_mi355x_config_info(c, info)
+        assert info[7] == lds and 2 * info[7] <= 160 * 1024          # exactly the two stages: two workgroups per CU
+    sys.path.insert(0, str(PKG))
+    from tools.update_tuned_table import form_text
+    import bench
+
+    assert form_text(1 | 0x20000) == "" and form_text(2 | 0x10000) == " fused split-K"
+    assert form_text(1 | 0x80000) == " K stagger per XCD" and form_text(4 | 0x80000 | 0x100000) == " two-pass split-K, K stagger per XCD, NT loads of the streamed operand"
+    assert form_text(1 | 0x200000 | 0x20000) == " phase offset"
+    d = bench.plan_dict(b"q256x256_w2x2", 2 | 0x10000 | 0x20000 | 0x80000 | 0x200000, 4)
+    assert d == {"config": "q256x256_w2x2", "splits": 2, "group_m": 4, "fused_split_k": True, "nt_store": True, "streamk": False,
+                 "xcd_stagger": True, "nt_loads": False, "phase_offset": True, "wave_priority": False, "phase_offset4": False}
+
+
+def test_first_use_selection_is_off_by_default_and_lists_launchable_candidates(lib):
+    """VERDICT r4 item 8 (the reference re-tunes in situ, kernels/h100_F32F16F16F32/64_4096_64.cu:623-690): opt-in, so the default
+    hot path stays a table probe.  Without a GPU only the candidate list can be checked: the table's plan first, at most three,
+    no duplicates, every geometry accepts the K, alternates of grid shapes come from the generated table whose rows name
+    existing geometries."""
+    lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
+    assert lib.hgemm_mi355x_set_insitu(0) == 0          # environment not set in the test run: it was off
+    cfg, sp, gm = (ctypes.c_int * 3)(), (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
+    c0, s0, g0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for mnk in ((4096, 4096, 4096), (16384, 256, 16384), (8192, 8192, 256), (64, 4096, 64), (1000, 520, 200), (4000, 4000, 4000), (65, 30, 100)):
+        n = lib.hgemm_mi355x_insitu_candidates(*mnk, cfg, sp, gm)
+        assert 1 <= n <= 3
+        lib.hgemm_mi355x_plan(*mnk, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0))
+        assert (cfg[0], sp[0], gm[0]) == (c0.value, s0.value, g0.value)
+        assert len({(cfg[i], sp[i], gm[i]) for i in range(n)}) == n
+        for i in range(n):
+            assert cfg[i] < 0 or lib.hgemm_mi355x_config_accepts_k(cfg[i], mnk[2]) == 1
+        assert lib.hgemm_mi355x_insitu_choice(*mnk, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0)) == 0   # nothing measured
+    rows = re.findall(r'\{(\d+), (\d+), (\d+), "([^"]+)", (\d+), (\d+)\}', (PKG / "csrc" / "hgemm_tuned_alternates.inc").read_text())
+    per_shape = {}
+    for m, n_, k, name, s, g in rows:
+        assert lib.hgemm_mi355x_config_by_name(name.encode()) >= 0, name
+        per_shape.setdefault((m, n_, k), []).append((name, s, g))
+    assert all(len(v) <= 2 and len(set(v)) == len(v) for v in per_shape.values())

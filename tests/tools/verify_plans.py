@@ -134,7 +134,7 @@ def randn_pass(a, L, stream, shapes) -> int:
                    "rows_checked": int(len(rows)), "reference": where, "inputs": "N(0,1)",
                    "plan": {"config": name.decode() if name else ("ragged" if cfg.value == -2 else "generic"), "splits": sp.value & 0xFFFF,
                             "fused": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000), "streamk": bool(sp.value & 0x40000),
-                            "rs_flags": (sp.value >> 19) & 3, "group_m": gm.value}}
+                            "rs_flags": (sp.value >> 19) & 3, "plan_flags": sp.value >> 19, "group_m": gm.value}}
             out_f.write(json.dumps(rec) + "\n")
             n_checks += 1
             n_fail += 0 if ok else 1
@@ -235,7 +235,7 @@ def main(argv=None) -> int:
                     if c is None:
                         rec["plan"] = {"config": name.decode() if name else ("ragged" if cfg.value == -2 else "generic"),
                                        "splits": sp.value & 0xFFFF, "fused": bool(sp.value & 0x10000), "nt_store": bool(sp.value & 0x20000),
-                                       "streamk": bool(sp.value & 0x40000), "rs_flags": (sp.value >> 19) & 3, "group_m": gm.value}
+                                       "streamk": bool(sp.value & 0x40000), "rs_flags": (sp.value >> 19) & 3, "plan_flags": sp.value >> 19, "group_m": gm.value}
                     else:
                         rec["plan"] = {"config": c["config"], "splits": c["splits"], "group_m": c["group_m"]}
                     out_f.write(json.dumps(rec) + "\n")
