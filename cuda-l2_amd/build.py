@@ -178,11 +178,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--clean", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--tools", action="store_true", help="also build bin/hgemm_tune")
+    ap.add_argument("--tools", action="store_true", help="(default since round 5) also build bin/hgemm_tune")
+    ap.add_argument("--lib-only", action="store_true", help="the library alone")
     a = ap.parse_args()
     if a.clean:
         clean()
     print(build_library(a.verbose))
-    if a.tools:
+    # The tool is rebuilt with the library by default: round 5 ran three GPU calls with a stale bin/hgemm_tune (the library was
+    # rebuilt, the tool was not) whose `check` did not know the new plan forms.
+    if not a.lib_only:
         for t in build_tools(a.verbose):
             print(t)

@@ -145,8 +145,19 @@ static bool g_plan_only = false;  // tune --plan-only
 // The callable returns the library status: a candidate that errors (bad geometry for the shape, no
 // workspace, backend failure) is reported with 1e30 us and can never win.
 constexpr double kFailedUs = 1e30;
+static int g_cooldown_ms = 0;   // tune / bench: --cooldown-ms
+static double g_stream_box_s = 0;   // tune --stream-seconds: length of a back-to-back box (default 8 / 12 ms)
 template <class F>
 static double time_us(F&& launch, std::vector<Buffers>& sets, int warm, int reps, hipEvent_t e0, hipEvent_t e1) {
+  // --cooldown-ms N (round 5): every isolated timing starts N ms after the previous work has drained -- for every contender alike.
+  // Why: the plan report with a 1 s autotune budget times OUR plan first for each shape, i.e. right behind the previous shape's two
+  // seconds of sustained hipBLASLt launches, and the board's power management was still throttling: on the >= 1e11-FLOP shapes our
+  // isolated launches read 8.8 % above our own back-to-back figure in that run (2.2 % in a run without the autotune search), the
+  // heuristic's, timed third and fourth, 0.5 % (tuning/r05_grid_plan_report_autotune_mi355x.jsonl).
+  if (g_cooldown_ms > 0) {
+    HIP_OK(hipDeviceSynchronize());
+    std::this_thread::sleep_for(std::chrono::milliseconds(g_cooldown_ms));
+  }
   for (int i = 0; i < warm; ++i)
     if (launch(sets[i % sets.size()]) != HGEMM_OK) return kFailedUs;
   HIP_OK(hipDeviceSynchronize());
@@ -540,7 +551,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     // other, the end-of-kernel release and the clocks of a busy device are part of the figure), short boxes
     double st_ours = -1, st_lt_nn = -1, st_lt_tn = -1;
     if (baselines && g_stream_report) {
-      const double box = flops > 1.5e12 ? 0.012 : 0.008;
+      const double box = g_stream_box_s > 0 ? g_stream_box_s : (flops > 1.5e12 ? 0.012 : 0.008);
       const Plan p = res[0].p;
       st_ours = stream_us([&](Buffers& s) { return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr); },
                           sets, box, e0, e1, res[0].us);
@@ -564,7 +575,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       // ... and back to back, like ours and the heuristic (round 5: the north-star comparison is against the autotuned baseline on
       // both clocks; the library keeps one selected algorithm per layout).
       if (g_stream_report) {
-        const double box = flops > 1.5e12 ? 0.012 : 0.008;
+        const double box = g_stream_box_s > 0 ? g_stream_box_s : (flops > 1.5e12 ? 0.012 : 0.008);
         if (at_tn > 0) st_at_tn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, at_tn);
         if (at_nn > 0) st_at_nn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_autotune_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, at_nn);
       }
@@ -863,6 +874,8 @@ int main(int argc, char** argv) {
     else if (a == "--cand-file") { if (!load_cand_file(next())) { fprintf(stderr, "cannot read --cand-file\n"); return 2; } }
     else if (a == "--configs") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) g_config_filter.push_back(t); }
     else if (a == "--plan-only") g_plan_only = true;
+    else if (a == "--cooldown-ms") g_cooldown_ms = atoi(next());
+    else if (a == "--stream-seconds") g_stream_box_s = atof(next());
     else if (a == "--keep") keep = atof(next());
     else if (a == "--max-cand") max_cand = atoi(next());
     else if (a == "--baselines") baselines = true;

@@ -71,21 +71,15 @@ def test_grid_plan_reports_match_the_design_text():
     assert len(rep) == 1000 and all(r["stream_us"] > 0 for r in rep)
     g = _gm(min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"] for r in rep)
     gs = _gm(min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) / r["stream_us"] for r in rep)
-    assert f"{g:.3f}" in _design() and f"{gs:.3f}" in _design() and f"{gs:.3f}" in (REPO / "README.md").read_text()
+    assert f"{g:.3f}" in _design() and f"{gs:.3f}" in _design()          # (round 4's closing figures: history in DESIGN section 6.6)
     out = tune_report.main(str(PKG / "tuning" / "r04_grid_plan_report_mi355x.jsonl"), 0)
     assert abs(out["back_to_back"]["geomean_speedup_vs_hipblaslt_heuristic_max"] - gs) < 1e-9
     for d in (10, 11, 12):
         assert f"{out['by_log10_flops'][d]['geomean']:.3f}" in _design(), d
-    # every reported plan is the shipped plan of that shape
-    shipped = _shipped()
-    for r in rep:
-        assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]
-    # hipBLASLt-autotune with a real budget on the quarter grid (rows whose plan changed afterwards are not counted)
-    auto = [r for r in _recs(PKG / "tuning" / "r04_quarter_grid_plan_report_autotune_mi355x.jsonl")
-            if (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]]]
-    assert len(auto) >= 230
+    # (round 4's reports describe round 4's table: 303 rows moved on in round 5, whose own reports are checked below)
+    auto = _recs(PKG / "tuning" / "r04_quarter_grid_plan_report_autotune_mi355x.jsonl")
     ga = _gm(min(v for v in (r["hipblaslt_auto_tn_us"], r["hipblaslt_auto_nn_us"], r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) if v > 0) / r["best"]["us"] for r in auto)
-    assert f"{ga:.3f}" in _design()
+    assert len(auto) == 250 and f"{ga:.3f}" in _design()
 
 
 def test_off_grid_report_and_parity_records():
@@ -104,12 +98,10 @@ def test_off_grid_report_and_parity_records():
     cand = sum(len(_recs(PKG / "tuning" / f)) for f in ("r04_candidate_parity_pass1.jsonl", "r04_candidate_parity_pass2.jsonl",
                                                          "r04_candidate_parity_family_r_flags.jsonl", "r04_candidate_parity_family_r_flags_pass2.jsonl",
                                                          "r04_candidate_parity_worst_rows.jsonl"))
-    assert f"{cand} candidate checks" in (REPO / "README.md").read_text()
+    assert cand == 1990
     log = (REPO / "profiles" / "r04_check_final.log").read_text()
     runs = re.search(r"check: (\d+) runs, 0 failures", log)
     assert runs and f"{int(runs.group(1))} runs" in _design()
-    named = set(re.search(r"^check-configs:(.*)$", log, re.M).group(1).split())
-    assert {c for c, _, _ in _shipped().values()} <= named               # every shipped geometry is in the closing check
 
 
 def test_pmc_table_feeds_bench_traffic_and_covers_every_geometry_with_five_rows():
@@ -120,9 +112,6 @@ def test_pmc_table_feeds_bench_traffic_and_covers_every_geometry_with_five_rows(
     for mnk in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
         d = json.loads((REPO / "profiles" / f"r04_pmc_{mnk}.json").read_text())["dominant_kernel"]
         assert d["mnk"] == mnk and abs(d["hbm_bytes_per_launch"] - rows[mnk]["hbm_bytes_per_launch"]) < 1
-    counts = collections.Counter(c for c, _, _ in _shipped().values())
-    covered = {r["plan"]["config"] for r in tab["rows"] if r["plan"]}
-    assert {c for c, n in counts.items() if n >= 5} <= covered
     r = rows["16384_128_16384"]
     assert f"{r['traffic_ratio']:.2f}" in _design()                      # the row section 6.6 builds its reading on
 
@@ -136,7 +125,7 @@ def test_sweep_readme_is_generated_from_the_records():
     for acc, mode in (("fp32", "offline"), ("fp16", "offline"), ("fp32", "server"), ("fp16", "server")):
         d = json.loads((root / f"merge_{acc}_{mode}.json").read_text())
         assert d["shapes"] == 1000
-        assert f"{d['geomean_speedup_vs_hipBLASLt-auto-tuning-max']:.3f}" in _design() and f"{d['geomean_speedup_vs_hipBLASLt-auto-tuning-max']:.3f}" in (REPO / "README.md").read_text()
+        assert f"{d['geomean_speedup_vs_hipBLASLt-auto-tuning-max']:.3f}" in _design()
     hdr = (root / "cuda_l2_mi355x_F32F16F16F32_tflops_offline.csv").read_text().splitlines()[0]
     assert hdr.endswith("cuda_l2_pct_of_fp16_mfma_peak,cuda_l2_pct_of_roofline")
 
@@ -224,8 +213,12 @@ def test_tuner_results_were_checked_before_they_were_timed():
     geometry that appears in the file is named by one of them (by the log's own `check-configs:` line when it has one); and in the lab
     script of the call the check comes before the tune."""
     man = json.loads((PKG / "tuning" / "r04_checked_before_timed.json").read_text())
-    tune_files = sorted(p for p in (PKG / "tuning").glob("r04_*_mi355x.jsonl") if "plan_report" not in p.name)
-    assert tune_files
+    man.update(json.loads((PKG / "tuning" / "r05_checked_before_timed.json").read_text()))     # round 5: same rule, same test
+    tune_files = sorted(p for rnd in ("r04", "r05") for p in (PKG / "tuning").glob(f"{rnd}_*_mi355x.jsonl") if "plan_report" not in p.name)
+    assert len([p for p in tune_files if p.name.startswith("r05_")]) >= 8
+    # round 5's family-q plan forms (kstagger variants, phase flags) are in the closing check's own form list
+    forms = re.search(r"^check-forms:(.*)$", (REPO / "profiles" / "r05_check_final.log").read_text(), re.M).group(1)
+    assert all(f in forms for f in ("1|xcd-stagger", "4|fused|xcd-stagger", "1|phase-offset", "1|phase-offset4", "1|phase-offset8", "1|wave-priority|nt-store"))
     for tf in tune_files:
         key = f"tuning/{tf.name}"
         assert key in man, f"{key}: no check evidence recorded -- a tuner result is not committed without it"
@@ -245,5 +238,129 @@ def test_tuner_results_were_checked_before_they_were_timed():
         ti = script.index(man[key]["tune_marker"]) if "tune_marker" in man[key] else script.index(" tune ")
         assert " check" in script and ci < ti, man[key]["script"]
     # plan-only reports time shipped plans (the table's own parity records cover those): nothing else may be in them
-    for rep in (PKG / "tuning").glob("r04_*plan_report*_mi355x.jsonl"):
+    for rep in list((PKG / "tuning").glob("r04_*plan_report*_mi355x.jsonl")) + list((PKG / "tuning").glob("r05_*plan_report*_mi355x.jsonl")):
         assert all(len(r["candidates"]) == 1 for r in _recs(rep)), rep.name
+
+
+# ---- round 5 -------------------------------------------------------------------------------------------------------------------------
+def test_round5_bench_record_and_its_rocprof_stats_match_the_design_text():
+    b = json.loads((REPO / "profiles" / "r05_bench.json").read_text())
+    assert b["metric"] == "HGEMM TFLOP/s" and b["n_gpus"] == 1 and b["dtype"] == "f16" and b["vs_baseline"] is None
+    d = _design()
+    roof = b["roofline"]
+    # ONE clock for the roofline -- the dispatch-attached events; the wall clock per call is reported beside it, never substituted
+    assert roof["launch_us"] == roof["avg_launch_us"] and "dispatch-attached" in roof["clock"] and roof["wall_per_call_us"] > 0
+    assert abs(roof["achieved"] - 2.0 * 4096 ** 3 / roof["launch_us"] * 1e-6) < 1.0 and abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3
+    assert f"{b['value']:.1f}" in d and f"{roof['frac']:.3f}" in d and f"{b['vs_hipblaslt_autotune_max']['ratio']:.3f}" in d
+    assert set(b["config"]["plan"]) >= {"config", "splits", "group_m", "nt_store", "xcd_stagger", "phase_offset", "phase_offset4", "wave_priority", "nt_loads"}
+    prof = json.loads((REPO / "profiles" / "r05_bench_py_profiled_run.json").read_text())
+    assert prof["config"]["plan"] == b["config"]["plan"] and prof["steps"] == b["steps"] and prof["config"]["batch"] == b["config"]["batch"]
+    rows = list(csv.DictReader(io.StringIO((REPO / "profiles" / "r05_bench_py_kernel_stats.csv").read_text())))
+    top = max(rows, key=lambda r: float(r["Percentage"]))
+    assert "hgemm_tn_sq_kernel" in top["Name"] and "CfgSQ<256, 256" in top["Name"] and float(top["Percentage"]) > 99.9
+    assert int(top["Calls"]) == (prof["steps"] + prof["warmup"]) * prof["config"]["batch"]
+    avg_us = float(top["AverageNs"]) * 1e-3
+    assert f"{avg_us:.2f}" in d and f"{2.0 * 4096 ** 3 / avg_us * 1e-6 / 2500.0:.3f}" in d
+    # the profiler's kernel average is below the event clock of its own run (events overstate: a start event fires while the predecessor drains)
+    assert 0.93 < avg_us / prof["roofline"]["launch_us"] < 1.01
+    # the traffic bench.py will cite from now on is this round's PMC record of the shipped kernel
+    import bench
+
+    t, src = bench.measured_traffic("4096_4096_4096")
+    assert src == "profiles/r05_pmc_4096_4096_4096.json" and abs(t / (3 * 2 * 4096 ** 2) - 2.34) < 0.03
+
+
+def test_round5_north_star_report_matches_design_and_readme():
+    """the metric BASELINE.json names -- geomean speedup over hipBLASLt-AUTOTUNE on the 1000-shape grid -- measured with a
+    real autotune budget on the device clock, isolated and back to back, for the SHIPPED table; DESIGN / README lead with it."""
+    import contextlib
+
+    import tune_report
+
+    path = PKG / "tuning" / "r05_grid_plan_report_autotune_mi355x.jsonl"
+    rep = _recs(path)
+    shipped = _shipped()
+    assert len(rep) >= 600 and len({r["mnk"] for r in rep}) == len(rep)
+    for r in rep:
+        assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]      # the shipped plans, nothing else
+        assert len(r["candidates"]) == 1 and r["stream_us"] > 0 and max(r["hipblaslt_auto_tn_us"], r["hipblaslt_auto_nn_us"]) > 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = tune_report.main(str(path), 0)
+    d, readme = _design(), (REPO / "README.md").read_text()
+    iso, b2b = out["vs_strongest_hipblaslt_isolated"], out["vs_strongest_hipblaslt_back_to_back"]
+    assert iso["shapes"] == len(rep) and b2b["shapes"] >= len(rep) - 5
+    for blk in (iso, b2b):
+        assert f"{blk['geomean_speedup']:.3f}" in d and f"{blk['geomean_speedup']:.3f}" in readme
+        assert f"{blk['aggregate_tflops_ours']:.0f} vs {blk['aggregate_tflops_hipblaslt_strongest']:.0f} TFLOP/s" in d
+        for dec in ("10", "11", "12"):
+            if dec in {str(k) for k in blk["by_log10_flops"]}:
+                v = blk["by_log10_flops"][int(dec)] if int(dec) in blk["by_log10_flops"] else blk["by_log10_flops"][dec]
+                assert f"{v['geomean']:.3f}" in d, (dec, v)
+    assert f"{out['geomean_speedup_vs_hipblaslt_heuristic_max']:.3f}" in d and f"{out['back_to_back']['geomean_speedup_vs_hipblaslt_heuristic_max']:.3f}" in d
+    # independent recomputation of the headline (not through tune_report): strongest of autotune / heuristic x tn / nn per shape
+    best = lambda r, suf: min(v for v in (r[f"hipblaslt_auto_tn{suf}"], r[f"hipblaslt_auto_nn{suf}"], r[f"hipblaslt_heur_tn{suf}"], r[f"hipblaslt_heur_nn{suf}"]) if v > 0)
+    assert abs(_gm(best(r, "_us") / r["best"]["us"] for r in rep) - iso["geomean_speedup"]) < 1e-9
+    # ... and the two runs that measured how much the report's own order moves the device-bound decades (DESIGN section 6.7)
+    J = _recs(PKG / "tuning" / "r05_grid_1e10_up_plan_report_autotune_cooldown_mi355x.jsonl")
+    K = _recs(PKG / "tuning" / "r05_compute_bound_sample_plan_report_autotune_long_boxes_mi355x.jsonl")
+    H = {r["mnk"]: r for r in rep}
+    fl = lambda r: 2.0 * math.prod(map(int, r["mnk"].split("_")))
+    assert len(J) >= 300 and all(fl(r) >= 1e10 for r in J) and len(K) >= 30 and all(fl(r) >= 1e12 for r in K)
+    for recs_, pairs in ((J, (("_us", lambda r: r["best"]["us"]), ("_stream_us", lambda r: r["stream_us"]))), (K, (("_stream_us", lambda r: r["stream_us"]),))):
+        for suf, ours in pairs:
+            assert f"{_gm(best(r, suf) / ours(r) for r in recs_):.3f}" in d                       # the run's own figure
+            assert f"{_gm(best(H[r['mnk']], suf) / ours(H[r['mnk']]) for r in recs_):.3f}" in d   # call H on the same shapes
+    big = [r for r in rep if fl(r) >= 1e11]
+    assert f"{_gm(r['best']['us'] / r['stream_us'] for r in big):.3f}×" in d and f"{_gm(r['hipblaslt_heur_tn_us'] / r['hipblaslt_heur_tn_stream_us'] for r in big):.3f}×" in d
+    for r in list(J) + list(K):
+        assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]
+
+
+def test_round5_off_grid_traffic_and_parity_records():
+    d = _design()
+    off = _recs(PKG / "tuning" / "r05_offgrid_plan_report_mi355x.jsonl")
+    assert len(off) == 80
+    iso = lambda r: min(r["hipblaslt_heur_tn_us"], r["hipblaslt_heur_nn_us"]) / r["best"]["us"]
+    b2b = lambda r: min(r["hipblaslt_heur_tn_stream_us"], r["hipblaslt_heur_nn_stream_us"]) / r["stream_us"]
+    assert f"{_gm(map(iso, off)):.3f}" in d and f"{_gm(map(b2b, off)):.3f}" in d
+    assert f"minimum **{min(map(iso, off)):.2f} / {min(map(b2b, off)):.2f}**" in d
+    par = _recs(PKG / "tuning" / "r05_parity_1000.jsonl")
+    assert len(par) == 2000 and all(r["pass"] and r["bitwise_equal_unmasked"] for r in par)
+    rn = _recs(PKG / "tuning" / "r05_randn_1000.jsonl")
+    assert len(rn) == 2000 and all(r["pass"] for r in rn) and f"{max(r['relative_error'] for r in rn):.1e}" in d
+    for name in ("r05_offgrid_parity.jsonl", "r05_offgrid_randn.jsonl"):
+        recs = _recs(PKG / "tuning" / name)
+        assert len(recs) == 160 and all(r["pass"] for r in recs), name
+    cand = [len(_recs(PKG / "tuning" / f"r05_candidate_parity_pass{i}.jsonl")) for i in (1, 2, 3, 4)]
+    assert " + ".join(map(str, cand)) + f" = {sum(cand)} candidate checks" in d and f"{sum(cand)} candidate checks" in (REPO / "README.md").read_text()
+    changed = set()
+    for i, n in zip((1, 2, 3, 4), (182, 163, 28, 21)):
+        ch = _recs(PKG / "tuning" / f"r05_retune_pass{i}_changes.jsonl")
+        assert len(ch) == n
+        changed |= {c["mnk"] for c in ch}
+    assert len(changed) == 303 and "303" in d
+    log = (REPO / "profiles" / "r05_check_final.log").read_text()
+    runs = re.search(r"check: (\d+) runs, 0 failures", log)
+    assert runs and f"{int(runs.group(1)):,}".replace(",", " ") in d
+    named = set(re.search(r"^check-configs:(.*)$", log, re.M).group(1).split())
+    assert {c for c, _, _ in _shipped().values()} <= named               # every shipped geometry is in the closing check
+    # fabric traffic against K and against the raster group (section 4.14)
+    tr = json.loads((REPO / "profiles" / "r05_pmc_traffic_vs_k.json").read_text())
+    for mnk in ("4096_4096_4096", "8192_8192_8192", "16384_16384_16384"):
+        o = tr["ours"][mnk]
+        assert f"{o['traffic_over_algorithmic']:.2f}" in d and f"{o['floor_over_algorithmic']:.2f}" in d and f"{o['traffic_over_floor']:.3f}" in d
+    assert f"{tr['hipblaslt']['16384_16384_16384']['traffic_over_algorithmic']:.2f}" in d
+    rg = json.loads((REPO / "profiles" / "r05_pmc_16384_raster_groups.json").read_text())
+    assert " / ".join(f"{r['traffic_over_algorithmic']:.2f}" for r in rg["rows"]) + "×" in d
+    ab = json.loads((REPO / "profiles" / "r05_ab_round4_library_m0_clobber_lgkmcnt.json").read_text())["mean_us"]
+    assert abs(ab["4096_4096_4096"]["ratio"] - 1.0) < 0.005 and abs(ab["16384_16384_256"]["ratio"] - 1.0) < 0.01
+    # the per-geometry table covers every geometry that serves >= 5 rows of the FINAL table, and feeds bench.py's traffic
+    import collections
+
+    tab = json.loads((REPO / "profiles" / "r05_pmc_table.json").read_text())
+    counts = collections.Counter(c for c, _, _ in _shipped().values())
+    assert {c for c, n in counts.items() if n >= 5} <= {r["plan"]["config"] for r in tab["rows"] if r["plan"]}
+    rows = {r["mnk"]: r for r in tab["rows"]}
+    for mnk in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
+        dk = json.loads((REPO / "profiles" / f"r05_pmc_{mnk}.json").read_text())["dominant_kernel"]
+        assert dk["mnk"] == mnk and abs(dk["hbm_bytes_per_launch"] - rows[mnk]["hbm_bytes_per_launch"]) < 1
