@@ -6,6 +6,7 @@
 #include "../../include/hgemm_mi355x.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -518,15 +519,18 @@ struct PlanTriple { int cfg, splits, group_m; };
 struct InsituChoice { int M, N, K; PlanTriple plan; };
 std::mutex g_insitu_mutex;
 std::vector<InsituChoice> g_insitu;
-int g_insitu_mode = -1;   // -1: environment not read yet
+std::atomic<int> g_insitu_mode{-1};   // -1: environment not read yet (atomic: calls may come from any thread)
 constexpr int kInsituReps = 5;
 
 bool insitu_enabled() {
-  if (g_insitu_mode < 0) {
+  int mode = g_insitu_mode.load(std::memory_order_relaxed);
+  if (mode < 0) {
     const char* e = getenv("HGEMM_MI355X_INSITU");
-    g_insitu_mode = (e && *e && *e != '0') ? 1 : 0;
+    int expected = -1;
+    g_insitu_mode.compare_exchange_strong(expected, (e && *e && *e != '0') ? 1 : 0);   // (a concurrent set_insitu wins)
+    mode = g_insitu_mode.load(std::memory_order_relaxed);
   }
-  return g_insitu_mode == 1;
+  return mode == 1;
 }
 
 // the plan + its alternates (at most three, no duplicates, every one launchable on this K)
@@ -954,7 +958,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
 
 int hgemm_mi355x_set_insitu(int enable) {
   const int old = insitu_enabled() ? 1 : 0;
-  g_insitu_mode = enable ? 1 : 0;
+  g_insitu_mode.store(enable ? 1 : 0);
   if (!enable) { std::lock_guard<std::mutex> lk(g_insitu_mutex); g_insitu.clear(); }   // a later enable measures again
   return old;
 }

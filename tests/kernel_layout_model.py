@@ -629,3 +629,48 @@ def staged_epilogue_roundtrip():
                 out[(lane, h, e)] = lds[a + 2 * e]
         rconf += bank_conflict_extra_cycles(addrs)
     return out, wconf, rconf
+
+
+# ---- family q, round 5: the K stagger of the stream cursors and the phase offset of the walk (hgemm_kernel_sq.hpp) -----------------
+def sq_stream_positions(items, xcd: int, stagger: bool, stage_bytes: int = 128, lead: int = 0):
+    """Mirror of SQ_LOAD_ITEM / SQ_STEP_CURSOR / SQ_ADVANCE for ONE LDS-DMA stream of a workgroup on XCD `xcd` walking `items`
+    = [(k_begin_bytes, nk stages), ...]: the (item index, kbyte) of every stream position in issue order.  The kstagger variant
+    enters an item `xcd * nk // 8` stages in and wraps behind its last stage; without it the walk is k_begin, k_begin + stage, ...
+    `lead` extra SQ_ADVANCE calls past the last position model the stream running ahead of the MFMAs: it must stay put."""
+    out = []
+    if not items:
+        return out
+    cur = None
+
+    def load(i):
+        kb, nk = items[i]
+        stag = (xcd & 7) * nk // 8 if stagger else 0
+        return {"item": i, "kt": 0, "nk": nk, "kbyte0": kb, "kwrap": nk - stag, "kbyte": kb + stag * stage_bytes}
+
+    cur = load(0)
+    total = sum(nk for _, nk in items)
+    for pos in range(total + lead):
+        out.append((cur["item"], cur["kbyte"]))
+        if cur["kt"] + 1 < cur["nk"]:                      # SQ_STEP_CURSOR
+            cur["kt"] += 1
+            cur["kbyte"] += stage_bytes
+            if stagger and cur["kt"] == cur["kwrap"]:
+                cur["kbyte"] = cur["kbyte0"]
+        elif cur["item"] + 1 < len(items):                 # SQ_LOAD_ITEM(next)
+            cur = load(cur["item"] + 1)
+        # else: past the last step of the last item the cursor stays put (the redundant pieces re-read a valid tile)
+    return out
+
+
+def sq_phase_delay_cycles(bm: int, bn: int, T: int, nk0: int, j: int, groups: int, walk_count: int, mi: int = 16) -> int:
+    """Mirror of the phase-offset prologue: cycles workgroup j of its XCD sleeps before its first LDS-DMA piece (rounded up to
+    the 1024-cycle s_sleep granule by the loop)."""
+    grp = j & (groups - 1)
+    if grp == 0 or walk_count <= 1:
+        return 0
+    period = nk0 * 2 * T * (32 if mi == 32 else 16) + bm * bn // 12
+    spacing = min(period // groups, bm * bn // 6)
+    c = 0
+    while c < spacing * grp:
+        c += 1024
+    return c

@@ -352,3 +352,56 @@ def test_stream_k_partition_covers_every_stage_once_with_two_slabs_per_workgroup
     share = tiles * ksteps / G
     slack = 2 * mn if ksteps >= 2 * mn else ksteps
     assert max(loads) <= share + slack + 1
+
+
+@pytest.mark.parametrize("stage_bytes", [128, 256])
+def test_family_q_k_stagger_visits_every_stage_once_and_both_streams_agree(stage_bytes):
+    """Round 5 (hgemm_kernel_sq.hpp, EPI_KSTAGGER): the rotation lives in the stream cursor.  For every XCD and every mix of stage counts
+    -- incl. fewer stages than XCDs, one-stage items, split-K chunks that start inside a row -- each item's stages are visited exactly
+    once, in the rotated order x * nk / 8, ..., nk - 1, 0, ...; the A and the B stream of a workgroup produce the SAME sequence (they
+    derive it from the same (XCD, stage count): round 3's knob offset them separately and was wrong for non-square members); a
+    stream that runs ahead of the last item stays on a valid position; without the flag the walk is the plain one."""
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n_items = int(rng.integers(1, 6))
+        items = [(int(rng.integers(0, 64)) * stage_bytes * 8, int(rng.integers(1, 70))) for _ in range(n_items)]
+        for xcd in range(8):
+            for stagger in (False, True):
+                a = klm.sq_stream_positions(items, xcd, stagger, stage_bytes)
+                b = klm.sq_stream_positions(items, xcd, stagger, stage_bytes, lead=3)      # the B stream / a stream running ahead
+                assert b[:len(a)] == a and all(p == a[-1] for p in b[len(a):])
+                pos = 0
+                for i, (kb, nk) in enumerate(items):
+                    seg = a[pos:pos + nk]
+                    pos += nk
+                    assert all(it == i for it, _ in seg)
+                    want = [kb + s * stage_bytes for s in range(nk)]
+                    got = [k for _, k in seg]
+                    assert sorted(got) == want                                           # every stage exactly once, none outside the item
+                    s0 = (xcd * nk // 8) if stagger else 0
+                    assert got == want[s0:] + want[:s0]                                  # the rotation, nothing else
+                assert pos == len(a)
+    # the eight XCDs of a one-round launch sit nk / 8 stages apart
+    starts = [klm.sq_stream_positions([(0, 256)], x, True)[0][1] // 128 for x in range(8)]
+    assert starts == [0, 32, 64, 96, 128, 160, 192, 224]
+
+
+def test_family_q_phase_offset_spacing():
+    """The phase offset of the persistent walk (HGEMM_PLAN_PHASE_OFFSET / _OFFSET4 / both): group 0 never waits, single-item walks never
+    wait, neighbouring groups are an equal share of the item period apart for a short K and an epilogue's length (BM x BN / 6 cycles)
+    apart for a long one -- so a 16384 x 16384 x 4096 walk pays ~11k cycles once, not half an item (the first version cost 4-5 %)."""
+    T = 64     # q256x256: FM x FN MFMA slots per interval
+    for groups in (2, 4, 8):
+        assert klm.sq_phase_delay_cycles(256, 256, T, 4, 0, groups, 16) == 0 and klm.sq_phase_delay_cycles(256, 256, T, 4, groups, groups, 16) == 0
+        assert klm.sq_phase_delay_cycles(256, 256, T, 4, 1, groups, 1) == 0
+    period_k256 = 4 * 2 * T * 16 + 256 * 256 // 12
+    assert abs(klm.sq_phase_delay_cycles(256, 256, T, 4, 1, 2, 16) - period_k256 // 2) <= 1024
+    assert abs(klm.sq_phase_delay_cycles(256, 256, T, 4, 3, 4, 16) - 3 * (period_k256 // 4)) <= 1024
+    cap = 256 * 256 // 6
+    for nk in (32, 64, 256):                                   # K = 2048 ... 16384: the cap applies as soon as a share of the period exceeds it
+        for groups in (2, 4, 8):
+            spacing = min((nk * 2 * T * 16 + 256 * 256 // 12) // groups, cap)
+            assert spacing == cap or (nk, groups) == (32, 8)
+            d = [klm.sq_phase_delay_cycles(256, 256, T, nk, j, groups, 16) for j in range(groups)]
+            assert d[0] == 0 and all(abs(d[g] - g * spacing) <= 1024 for g in range(groups)), (nk, groups, d)
+    assert klm.sq_phase_delay_cycles(256, 256, T, 64, 1, 2, 16) < (64 * 2 * T * 16) // 8      # far below half an item period
