@@ -128,7 +128,9 @@ struct CfgSQ : Cfg<BM_, BN_, WM_, WN_, MI_, 2> {
   // footprint admits two workgroups per CU (sp_reserve_agprs)
   // WGS = 2: "two-resident" member (round 5) -- its two stages fit twice into the CU's 160 KiB, its waves into half a SIMD's
   // register file: the plain-epilogue kernels then declare the stages and nothing else (no vote word, no staged epilogue), and the
-  // host launches 512 persistent workgroups: one workgroup's epilogue runs under the other's K loop without any schedule of ours.
+  // host launches 512 persistent workgroups.  Measured: the two workgroups of a CU do NOT end up with one's
+  // epilogue under the other's K loop (both stay in their XCD's lock-step) -- what they buy is two LDS-DMA and two MFMA streams per
+  // CU that overlap without a schedule of ours, which beats the register-staged family on the skinny shapes.
   static constexpr int WGS = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr int AGPRS = WGS == 2 ? Base::FM * Base::FN * ACC : 256;
 };
