@@ -344,6 +344,17 @@ def test_round5_off_grid_traffic_and_parity_records():
     assert runs and f"{int(runs.group(1)):,}".replace(",", " ") in d
     named = set(re.search(r"^check-configs:(.*)$", log, re.M).group(1).split())
     assert {c for c, _, _ in _shipped().values()} <= named               # every shipped geometry is in the closing check
+    # the phase-offset rows re-checked on a fresh box (section 4.14, call N): shipped plan against the same plan without the flag
+    gains = []
+    for r in _recs(PKG / "tuning" / "r05_phase_rows_recheck_mi355x.jsonl"):
+        fig = lambda c: math.sqrt(c["us"] * c["stream_us"])
+        ph = [c for c in r["candidates"] if c["splits"] & 0xA00000 and c.get("stream_us")]
+        pl = [c for c in r["candidates"] if not c["splits"] & 0xA00000 and c.get("stream_us")]
+        if ph and pl:
+            assert (ph[0]["config"], ph[0]["splits"], ph[0]["group_m"]) == _shipped()[r["mnk"]]
+            gains.append(fig(pl[0]) / fig(ph[0]))
+    assert len(gains) == 52 and f"+{(_gm(gains) - 1) * 100:.1f} % for the flag" in d
+    assert f"{sum(g > 1.015 for g in gains)} gain more than 1.5 %, {sum(g < 0.985 for g in gains)} lose more than 1.5 %" in d
     # fabric traffic against K and against the raster group (section 4.14)
     tr = json.loads((REPO / "profiles" / "r05_pmc_traffic_vs_k.json").read_text())
     for mnk in ("4096_4096_4096", "8192_8192_8192", "16384_16384_16384"):
