@@ -18,7 +18,7 @@ import pandas
 import torch
 
 from benchmarking_utils import run_all_perf_funcs_once
-from harness_common import (RESULT_VERSION, add_common_args, cpu_cores, destroy_baselines, init_baselines,
+from harness_common import (RESULT_VERSION, add_common_args, cpu_cores, destroy_baselines, init_baselines, insitu_report,
                             load_kernel, parse_mnk, percentile, seed_everything)
 
 torch.set_grad_enabled(False)
@@ -91,6 +91,10 @@ def run(args, extra: dict | None = None) -> dict:
     print("Warmup...")
     warm, warm_s = timed_loop(args.warmup_seconds, list(perf_funcs), False, args, m, n, k, pads)
     print(f"Warmup done: {len(warm)} iterations in {warm_s:.2f} seconds.")
+    # first-use plan selection (eval_one_file.sh --insitu): the first cuda_l2 call above timed the plan and its alternates
+    insitu = insitu_report(m, n, k) if hgemm is not None else None
+    if insitu is not None:
+        print(f"in-situ plan selection: {insitu}")
     print("Benchmarking...")
     records, _ = timed_loop(args.benchmark_seconds, list(perf_funcs), True, args, m, n, k, pads)
 
@@ -116,6 +120,8 @@ def run(args, extra: dict | None = None) -> dict:
               "device": args.device}
     if args.device == "cpu":
         result["cpu"] = cpu_cores()
+    if insitu is not None:
+        result["insitu"] = insitu
     result.update(extra or {})
     if cuda_l2_func_name is not None:
         print(f"speedup over {args.perf_func}: {merged[cuda_l2_func_name] / merged[names[0]]:.2f}x")

@@ -507,7 +507,7 @@ bool mfma_path_ok(const void* a, const void* bt, const void* c, int M, int N, in
 // shape times up to three plans on the call's own operands and stream -- the table's (or the planner's) plan and its
 // alternates: for a grid shape the oracle-verified runners-up of the last re-tune (hgemm_tuned_alternates.inc), for any shape the
 // plan with family q's K stagger / phase offset toggled (flags that cannot change a result's exactness) -- each once to warm up and
-// kInsituReps times under dispatch-attached events, and keeps the fastest for the process; an alternate must beat the plan by
+// kInsituReps times under dispatch-attached events, in interleaved rounds, and keeps the fastest for the (process, device); an alternate must beat the plan by
 // 3 % to replace it.  The call then runs the winner, so C holds exactly one plan's result.  That first call synchronises the
 // stream (it is meant for a warm-up phase: the harness's warm-up seconds, a model's first step); calls on a capturing stream and
 // every later call take the recorded choice without timing anything.  Default: off -- the hot path is the table probe.
@@ -516,11 +516,17 @@ const AltRow g_alt_rows[] = {
 #include "hgemm_tuned_alternates.inc"
     {0, 0, 0, nullptr, 0, 0}};
 struct PlanTriple { int cfg, splits, group_m; };
-struct InsituChoice { int M, N, K; PlanTriple plan; };
+// One record per (device, shape): boxes rank plans differently and so may the devices of one box.
+struct InsituChoice { int dev, M, N, K; PlanTriple plan; };
 std::mutex g_insitu_mutex;
-std::vector<InsituChoice> g_insitu;
-std::atomic<int> g_insitu_mode{-1};   // -1: environment not read yet (atomic: calls may come from any thread)
+std::vector<InsituChoice> g_insitu;      // the process's choices (guarded by g_insitu_mutex)
+std::atomic<unsigned> g_insitu_epoch{1}; // bumped when set_insitu(0) forgets them: invalidates the per-thread memos below
+std::atomic<int> g_insitu_mode{-1};      // -1: environment not read yet (atomic: calls may come from any thread)
 constexpr int kInsituReps = 5;
+// Steady state must not take a process-wide lock per GEMM: a thread remembers the choices it has used (direct-mapped on the
+// shape key like t_plan_memo; the mutex-guarded vector is only consulted on a memo miss).
+struct InsituMemo { unsigned epoch; int dev, M, N, K; PlanTriple plan; };
+thread_local InsituMemo t_insitu_memo[32] = {};
 
 bool insitu_enabled() {
   int mode = g_insitu_mode.load(std::memory_order_relaxed);
@@ -559,18 +565,40 @@ int insitu_candidates(int M, int N, int K, PlanTriple out[3]) {
   return n;
 }
 
-bool insitu_lookup(int M, int N, int K, PlanTriple* p) {
+inline InsituMemo& insitu_memo_slot(int dev, int M, int N, int K) {
+  const uint64_t key = shape_key(M, N, K) * 0x9E3779B97F4A7C15ull + (uint64_t)dev;
+  return t_insitu_memo[(key ^ (key >> 21) ^ (key >> 42)) & 31];
+}
+
+bool insitu_lookup(int dev, int M, int N, int K, PlanTriple* p) {
+  const unsigned epoch = g_insitu_epoch.load(std::memory_order_acquire);
+  InsituMemo& m = insitu_memo_slot(dev, M, N, K);
+  if (m.epoch == epoch && m.dev == dev && m.M == M && m.N == N && m.K == K) { *p = m.plan; return true; }
   std::lock_guard<std::mutex> lk(g_insitu_mutex);
   for (const InsituChoice& c : g_insitu)
-    if (c.M == M && c.N == N && c.K == K) { *p = c.plan; return true; }
+    if (c.dev == dev && c.M == M && c.N == N && c.K == K) {
+      *p = c.plan;
+      m = InsituMemo{epoch, dev, M, N, K, c.plan};
+      return true;
+    }
   return false;
 }
 
 // times the candidates on the call's operands; false (nothing recorded) when the stream captures or an event call fails
-bool insitu_select(const void* a, const void* b, const void* bt, void* c, int M, int N, int K, void* stream, PlanTriple* choice) {
+bool insitu_select(int dev, const void* a, const void* b, const void* bt, void* c, int M, int N, int K, void* stream, PlanTriple* choice) {
   hipStream_t s = (hipStream_t)stream;
+  // A capture on THIS stream means nothing may be timed.  (The legacy stream is not asked: the query itself would invalidate a
+  // global-mode capture of another stream, and so would the caller's launch on it.)  The event calls below would invalidate a
+  // global-mode capture that ANOTHER stream of this thread is recording: they run under the relaxed capture mode, as
+  // ensure_workspace's hipMalloc does.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return false;
+  struct RelaxedCapture {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool ok;
+    RelaxedCapture() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+    ~RelaxedCapture() { if (ok && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+  } relaxed;
   PlanTriple cand[3];
   const int n = insitu_candidates(M, N, K, cand);
   if (n == 0) return false;
@@ -578,29 +606,34 @@ bool insitu_select(const void* a, const void* b, const void* bt, void* c, int M,
   if (n > 1) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); (void)hipGetLastError(); return false; }
+    // Interleaved rounds: one launch of every candidate per round, so that all of them see the same clock /
+    // thermal history -- timing them one after the other right after a cold start favours whoever comes later.
+    float t[3][kInsituReps];
+    bool ok[3] = {true, true, true};
+    for (int r = -1; r < kInsituReps; ++r)   // round -1 warms every candidate up untimed
+      for (int i = 0; i < n; ++i) {
+        if (!ok[i]) continue;
+        if (r >= 0) { hgemm_mi355x::t_launch_timing.start = e0; hgemm_mi355x::t_launch_timing.stop = e1; }   // ride on the plan's own dispatch packets
+        ok[i] = hgemm_mi355x_launch(cand[i].cfg, cand[i].splits, cand[i].group_m, a, b, bt, c, M, N, K, K, K, N, stream) == HGEMM_OK;
+        if (ok[i] && r >= 0) ok[i] = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t[i][r], e0, e1) == hipSuccess;
+        if (!ok[i]) (void)hipGetLastError();
+      }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (!ok[0]) return false;
     double us[3] = {1e30, 1e30, 1e30};
     for (int i = 0; i < n; ++i) {
-      bool ok = hgemm_mi355x_launch(cand[i].cfg, cand[i].splits, cand[i].group_m, a, b, bt, c, M, N, K, K, K, N, stream) == HGEMM_OK;   // warm
-      float t[kInsituReps];
-      for (int r = 0; ok && r < kInsituReps; ++r) {
-        hgemm_mi355x::t_launch_timing.start = e0; hgemm_mi355x::t_launch_timing.stop = e1;   // ride on the plan's own dispatch packets
-        ok = hgemm_mi355x_launch(cand[i].cfg, cand[i].splits, cand[i].group_m, a, b, bt, c, M, N, K, K, K, N, stream) == HGEMM_OK &&
-             hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t[r], e0, e1) == hipSuccess;
-      }
-      if (!ok) { (void)hipGetLastError(); continue; }
-      std::sort(t, t + kInsituReps);
-      us[i] = (double)t[kInsituReps / 2] * 1e3;   // median
+      if (!ok[i]) continue;
+      std::sort(t[i], t[i] + kInsituReps);
+      us[i] = (double)t[i][kInsituReps / 2] * 1e3;   // median
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (us[0] >= 1e30) return false;
     for (int i = 1; i < n; ++i)
       if (us[i] < 0.97 * us[0] && us[i] < us[best]) best = i;   // an alternate has to beat the shipped plan by 3 %
   }
   *choice = cand[best];
   std::lock_guard<std::mutex> lk(g_insitu_mutex);
   for (const InsituChoice& ch : g_insitu)
-    if (ch.M == M && ch.N == N && ch.K == K) { *choice = ch.plan; return true; }   // another thread was faster: one choice per process
-  g_insitu.push_back({M, N, K, *choice});
+    if (ch.dev == dev && ch.M == M && ch.N == N && ch.K == K) { *choice = ch.plan; return true; }   // another thread was faster: one choice per (process, device)
+  g_insitu.push_back({dev, M, N, K, *choice});
   return true;
 }
 
@@ -609,7 +642,9 @@ int run(int acc, const void* a, const void* b, const void* bt, void* c, int M, i
   (void)acc;  // both accumulate modes use the fp32-accumulating MFMA (header comment)
   if (insitu_enabled() && a && c && bt && M > 0 && N > 0 && K > 0) {
     PlanTriple p;
-    if (insitu_lookup(M, N, K, &p) || insitu_select(a, b, bt, c, M, N, K, stream, &p))
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (insitu_lookup(dev, M, N, K, &p) || insitu_select(dev, a, b, bt, c, M, N, K, stream, &p))
       return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, a, b, bt, c, M, N, K, K, K, N, stream);
   }
   int cfg, splits, group_m;
@@ -946,7 +981,12 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
       }
     }
     // persistent families walk their work items themselves: one resident wave of workgroups
-    const long launch_grid = (e.persistent_wgs > 0) ? std::min<long>(grid, e.persistent_wgs) : grid;
+    long launch_grid = (e.persistent_wgs > 0) ? std::min<long>(grid, e.persistent_wgs) : grid;
+    // A two-resident member (persistent_wgs = 512) whose single-launch split-K variant no longer fits twice into a CU's 160 KiB
+    // -- the fused epilogue adds the 64-byte vote word to the stage area: q192x128 / q128x192 with 80 KiB of stages -- is resident
+    // once per CU: 512 workgroups would run as two sequential waves of 256, each paying its own prologue.  One wave of 256 walks
+    // the same items.
+    if (epi == EPI_FUSED && e.persistent_wgs > kCUs && 2L * (e.lds_bytes + 64) > 160L * 1024) launch_grid = std::min<long>(launch_grid, kCUs);
     set_raster_div(g);
     e.launch(g, (int)launch_grid, s, epi, timing_slot(true, epi != EPI_SLAB));
     if (epi == EPI_SLAB) launch_splitk_reduce(g.partial, g.C, M, N, ldc, splits, s, timing_slot(false, true));
@@ -959,9 +999,15 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
 int hgemm_mi355x_set_insitu(int enable) {
   const int old = insitu_enabled() ? 1 : 0;
   g_insitu_mode.store(enable ? 1 : 0);
-  if (!enable) { std::lock_guard<std::mutex> lk(g_insitu_mutex); g_insitu.clear(); }   // a later enable measures again
+  if (!enable) {   // a later enable measures again (the epoch retires every thread's memo of the old choices)
+    std::lock_guard<std::mutex> lk(g_insitu_mutex);
+    g_insitu.clear();
+    g_insitu_epoch.fetch_add(1, std::memory_order_release);
+  }
   return old;
 }
+
+int hgemm_mi355x_insitu_enabled(void) { return insitu_enabled() ? 1 : 0; }
 
 int hgemm_mi355x_insitu_candidates(int M, int N, int K, int config_id[3], int splits[3], int group_m[3]) {
   if (M <= 0 || N <= 0 || K <= 0 || !config_id || !splits || !group_m) return 0;
@@ -973,7 +1019,9 @@ int hgemm_mi355x_insitu_candidates(int M, int N, int K, int config_id[3], int sp
 
 int hgemm_mi355x_insitu_choice(int M, int N, int K, int* config_id, int* splits, int* group_m) {
   PlanTriple p;
-  if (!config_id || !splits || !group_m || !insitu_lookup(M, N, K, &p)) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  if (!config_id || !splits || !group_m || !insitu_lookup(dev, M, N, K, &p)) return 0;
   *config_id = p.cfg; *splits = p.splits; *group_m = p.group_m;
   return 1;
 }

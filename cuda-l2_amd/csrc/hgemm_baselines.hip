@@ -10,8 +10,13 @@
 // Differences, on purpose: the workspace is an explicit size_t (the reference's heuristic path
 // overflows `20 * 1024 * 1024 * 1024` to 0, hgemm_cublaslt_heuristic.cu:18), and the autotune is
 // time-boxed for very large shapes (HGEMM_AUTOTUNE_MAX_SECONDS, default 30 s per layout).
+// Round 6: the search result can be kept on disk (HGEMM_AUTOTUNE_CACHE=<file> or hgemm_hipblaslt_autotune_set_cache): one line per
+// (layout, M, N, K, compute type) with the winner's hipBLASLt solution index, so that a 1000-shape sweep pays the search once per
+// problem instead of once per (sweep, process) -- the reference re-runs it in every benchmarking process
+// (benchmarking_offline.py:71-84), which is what boxed rounds 2-4's sweeps to a 0.05 s search.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 #include <rocblas/rocblas.h>
 
 #include <algorithm>
@@ -19,8 +24,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <numeric>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "../../include/hgemm_mi355x.h"
@@ -235,6 +243,100 @@ double median_of(std::vector<float>& v) {
   return (v.size() % 2 == 0) ? 0.5 * (v[mid] + v[mid - 1]) : v[mid];
 }
 
+// ---- on-disk cache of autotune winners ----------------------------------------------------------------------------------------
+// Text, one record per line:  tn M N K compute16 algo_index best_ms candidates warm timed budget_s solution_name
+// The solution index is hipBLASLt's own (hipblaslt_ext::getIndexFromAlgo / getAlgosFromIndex): valid for the library build that
+// wrote it -- a record whose index the running library does not accept for the problem (matmulIsAlgoSupported) is ignored and the
+// search runs again.  A record is reused only if it was searched with at least the budget the caller asks for now.
+struct AutotuneRecord {
+  int tn, M, N, K, compute16, algo_index, candidates, warm, timed;
+  double best_ms, budget_s;
+  std::string solution;
+};
+std::mutex g_cache_mutex;
+std::string g_cache_path;
+bool g_cache_path_set = false;     // hgemm_hipblaslt_autotune_set_cache was called (overrides the environment)
+bool g_cache_loaded = false;
+std::vector<AutotuneRecord> g_cache;
+int g_cache_hits = 0, g_cache_misses = 0;
+int g_last_from_cache[2] = {0, 0};   // [tn]: the last find_best of this layout was served from the cache
+
+double autotune_budget_s() {
+  const char* env = getenv("HGEMM_AUTOTUNE_MAX_SECONDS");
+  return env ? atof(env) : 30.0;
+}
+
+void cache_load_locked() {
+  if (g_cache_loaded) return;
+  g_cache_loaded = true;
+  g_cache.clear();
+  if (!g_cache_path_set) {
+    const char* env = getenv("HGEMM_AUTOTUNE_CACHE");
+    g_cache_path = env ? env : "";
+  }
+  if (g_cache_path.empty()) return;
+  FILE* f = fopen(g_cache_path.c_str(), "r");
+  if (!f) return;
+  char line[1024];
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] == '#' || line[0] == '\n') continue;
+    AutotuneRecord r;
+    char name[768] = "";
+    if (sscanf(line, "%d %d %d %d %d %d %lf %d %d %d %lf %767s", &r.tn, &r.M, &r.N, &r.K, &r.compute16, &r.algo_index, &r.best_ms,
+               &r.candidates, &r.warm, &r.timed, &r.budget_s, name) < 11) continue;
+    r.solution = name;
+    g_cache.push_back(r);   // (a later line of the same problem supersedes an earlier one: lookups scan from the back)
+  }
+  fclose(f);
+}
+
+bool cache_lookup(bool tn, int M, int N, int K, bool compute16, double budget_s, AutotuneRecord* out) {
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  cache_load_locked();
+  for (auto it = g_cache.rbegin(); it != g_cache.rend(); ++it)
+    if (it->tn == (int)tn && it->M == M && it->N == N && it->K == K && it->compute16 == (int)compute16) {
+      if (it->budget_s + 1e-9 < budget_s) return false;   // searched with a smaller box than asked for now: search again
+      *out = *it;
+      return true;
+    }
+  return false;
+}
+
+void cache_store(const AutotuneRecord& r) {
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  cache_load_locked();
+  g_cache.push_back(r);
+  if (g_cache_path.empty()) return;
+  FILE* f = fopen(g_cache_path.c_str(), "a");
+  if (!f) return;
+  if (ftell(f) == 0)
+    fprintf(f, "# hipBLASLt autotune winners (hgemm_baselines.hip): tn M N K compute16 algo_index best_ms candidates warm timed budget_s solution\n");
+  fprintf(f, "%d %d %d %d %d %d %.6f %d %d %d %.3f %s\n", r.tn, r.M, r.N, r.K, r.compute16, r.algo_index, r.best_ms, r.candidates,
+          r.warm, r.timed, r.budget_s, r.solution.empty() ? "-" : r.solution.c_str());
+  fclose(f);
+}
+
+// the cached winner as a usable algo for the prepared problem p, or false
+bool cache_apply(LtProblem& p, const AutotuneRecord& r) {
+  if (r.algo_index < 0) return false;
+  std::vector<int> idx{r.algo_index};
+  std::vector<hipblasLtMatmulHeuristicResult_t> res;
+  if (hipblaslt_ext::getAlgosFromIndex(g_auto.handle, idx, res) != HIPBLAS_STATUS_SUCCESS || res.empty()) return false;
+  const float alpha32 = 1.0f, beta32 = 0.0f;
+  const f16 alpha16 = (f16)1.0f, beta16 = (f16)0.0f;
+  const bool h = p.compute16;
+  size_t ws = 0;
+  if (hipblaslt_ext::matmulIsAlgoSupported(g_auto.handle, p.op, h ? (const void*)&alpha16 : (const void*)&alpha32, p.b_desc, p.a_desc,
+                                           h ? (const void*)&beta16 : (const void*)&beta32, p.c_desc, p.c_desc, res[0].algo,
+                                           ws) != HIPBLAS_STATUS_SUCCESS || ws > kLtWorkspaceBytes)
+    return false;
+  p.algo = res[0].algo;
+  p.have_algo = true;
+  p.candidates = r.candidates;
+  p.best_ms = r.best_ms;
+  return true;
+}
+
 int autotune_find(bool tn, int M, int N, int K, int acc) {
   if (M <= 0 || N <= 0 || K <= 0) return HGEMM_ERR_BAD_ARG;
   if (!g_auto.handle) return HGEMM_ERR_NOT_READY;
@@ -242,6 +344,16 @@ int autotune_find(bool tn, int M, int N, int K, int acc) {
   std::vector<hipblasLtMatmulHeuristicResult_t> cands;
   int st = lt_prepare(g_auto, p, tn, M, N, K, acc, 100, cands);
   if (st != HGEMM_OK) return st;
+  g_last_from_cache[tn ? 1 : 0] = 0;
+  {
+    AutotuneRecord rec;
+    if (cache_lookup(tn, M, N, K, p.compute16, autotune_budget_s(), &rec) && cache_apply(p, rec)) {
+      g_last_from_cache[tn ? 1 : 0] = 1;
+      ++g_cache_hits;
+      return HGEMM_OK;
+    }
+    ++g_cache_misses;
+  }
   int n_algo = (int)cands.size();
   {
     // Time box, part 1 (before anything is allocated): when one round over all candidates would already take more
@@ -329,6 +441,16 @@ int autotune_find(bool tn, int M, int N, int K, int acc) {
   p.have_algo = true;
   p.candidates = n_algo;
   p.best_ms = best_ms;
+  {
+    AutotuneRecord rec;
+    rec.tn = tn; rec.M = M; rec.N = N; rec.K = K; rec.compute16 = p.compute16;
+    rec.algo_index = hipblaslt_ext::getIndexFromAlgo(p.algo);
+    rec.best_ms = best_ms; rec.candidates = n_algo; rec.warm = warm; rec.timed = timed; rec.budget_s = budget;
+    rec.solution = hipblaslt_ext::getSolutionNameFromAlgo(g_auto.handle, p.algo);
+    for (char& ch : rec.solution) if (ch == ' ' || ch == '\n' || ch == '\t') ch = '_';
+    if (rec.solution.size() > 700) rec.solution.resize(700);
+    if (rec.algo_index >= 0) cache_store(rec);
+  }
   return HGEMM_OK;
 }
 
@@ -398,6 +520,21 @@ int hgemm_hipblaslt_autotune_nn(const void* a, const void* b, void* c, int M, in
 }
 int hgemm_hipblaslt_autotune_tn(const void* a, const void* bt, void* c, int M, int N, int K, int acc, void* s) {
   return autotune_run(true, a, bt, c, M, N, K, acc, s);
+}
+int hgemm_hipblaslt_autotune_set_cache(const char* path) {
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  g_cache_path = path ? path : "";
+  g_cache_path_set = true;
+  g_cache_loaded = false;   // (re)read on the next find_best
+  return HGEMM_OK;
+}
+int hgemm_hipblaslt_autotune_from_cache(int tn) { return g_last_from_cache[tn ? 1 : 0]; }
+int hgemm_hipblaslt_autotune_cache_stats(int* hits, int* misses) {
+  if (hits) *hits = g_cache_hits;
+  if (misses) *misses = g_cache_misses;
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  cache_load_locked();
+  return (int)g_cache.size();
 }
 int hgemm_hipblaslt_autotune_candidates(int tn) { return (tn ? g_auto.tn : g_auto.nn).candidates; }
 double hgemm_hipblaslt_autotune_best_ms(int tn) { return (tn ? g_auto.tn : g_auto.nn).best_ms; }

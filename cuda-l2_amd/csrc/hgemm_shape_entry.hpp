@@ -22,7 +22,9 @@
   extern "C" int cuda_l2_mi355x_shape_launch(const void* a, const void* b, const void* b_col_major,     \
                                              void* c, int M, int N, int K, void* stream) {              \
     static const int cfg = hgemm_mi355x_config_by_name(CONFIG_NAME);                                    \
-    if (M == (M_) && N == (N_) && K == (K_) && cfg >= 0)                                                \
+    /* first-use selection on (HGEMM_MI355X_INSITU=1 / eval_one_file.sh --insitu): the library entry times this plan and */    \
+    /* its alternates on the first call and keeps the winner; off (default): the pinned plan, one table-free launch      */    \
+    if (M == (M_) && N == (N_) && K == (K_) && cfg >= 0 && !hgemm_mi355x_insitu_enabled())              \
       return hgemm_mi355x_launch(cfg, (SPLITS), (GROUP_M), a, b, b_col_major, c, M, N, K, K, K, N,      \
                                  stream);                                                               \
     /* tensors of another size (or a retired geometry name): let the library plan it */                 \

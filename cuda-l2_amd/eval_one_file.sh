@@ -6,6 +6,10 @@
 #       --benchmark_seconds 10 --base_dir ./results/64_4096_64 --gpu_device_id 0 --mode offline
 #   ... --mode server --target_qps 100
 #   ... --defense          additionally run the self-audit (defense.py) before the benchmarks
+#   ... --insitu           first-use plan selection on this box (HGEMM_MI355X_INSITU=1): the first cuda_l2 call of every process
+#                          -- it falls into the warm-up seconds -- times the shipped plan and its oracle-verified alternates and
+#                          keeps the fastest, as the reference's H100 kernels tune on first invocation
+#                          (kernels/h100_F32F16F16F32/64_4096_64.cu:623-690,702-721); benchmark_result_*.json then carry "insitu"
 cd "$(dirname "$0")" || exit 1
 
 MODE="offline"; TARGET_QPS=""; DEVICE_TYPE="mi355x"; GPU_DEVICE_ID=0; DEFENSE=0
@@ -21,6 +25,7 @@ while [[ $# -gt 0 ]]; do
         --mode) MODE="$2"; shift 2 ;;
         --target_qps) TARGET_QPS="$2"; shift 2 ;;
         --defense) DEFENSE=1; shift 1 ;;
+        --insitu) export HGEMM_MI355X_INSITU=1; shift 1 ;;
         *) echo "Unknown option: $1"; exit 1 ;;
     esac
 done

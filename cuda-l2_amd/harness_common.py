@@ -98,6 +98,33 @@ def destroy_baselines(hgemm) -> None:
     torch.cuda.synchronize()
 
 
+def insitu_report(m: int, n: int, k: int) -> dict | None:
+    """What the library's first-use plan selection did for (m, n, k) in THIS process, or None when it is off
+    (HGEMM_MI355X_INSITU unset / 0).  The reference's counterpart is the first-call autotune inside a kernel file
+    (kernels/h100_F32F16F16F32/64_4096_64.cu:623-690,702-721), which reports nothing; here the benchmark JSON names the
+    candidates and the choice so that a result can be traced to a plan."""
+    import ctypes
+    from pathlib import Path
+
+    flag = os.environ.get("HGEMM_MI355X_INSITU", "")
+    if not flag or flag[0] == "0":
+        return None
+    lib = ctypes.CDLL(str(Path(__file__).resolve().parent / "lib" / "libhgemm_mi355x.so"))   # already mapped by hgemm_lib
+    lib.hgemm_mi355x_config_name.restype = ctypes.c_char_p
+    cfg, sp, gm = (ctypes.c_int * 3)(), (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
+    ncand = lib.hgemm_mi355x_insitu_candidates(m, n, k, cfg, sp, gm)
+
+    def plan(c, s, g):
+        name = lib.hgemm_mi355x_config_name(c)
+        return {"config": name.decode() if name else str(c), "splits": int(s), "group_m": int(g)}
+
+    c0, s0, g0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    chosen = lib.hgemm_mi355x_insitu_choice(m, n, k, ctypes.byref(c0), ctypes.byref(s0), ctypes.byref(g0))
+    return {"enabled": bool(lib.hgemm_mi355x_insitu_enabled()), "candidates": [plan(cfg[i], sp[i], gm[i]) for i in range(ncand)],
+            "chosen": plan(c0.value, s0.value, g0.value) if chosen == 1 else None,
+            "kept_table_plan": bool(chosen == 1 and (c0.value, s0.value, g0.value) == (cfg[0], sp[0], gm[0]))}
+
+
 def percentile(values, q: float) -> float:
     if not len(values):
         return float("nan")

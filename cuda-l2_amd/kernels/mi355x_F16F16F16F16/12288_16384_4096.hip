@@ -1,5 +1,5 @@
 // M=12288 N=16384 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X (round 4): 1124.2 us, 1467.0 TFLOP/s (back to back 1120.2 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X (round 5): 1124.2 us, 1467.0 TFLOP/s (back to back 1120.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

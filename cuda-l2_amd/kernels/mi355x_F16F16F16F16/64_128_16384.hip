@@ -1,5 +1,5 @@
 // M=64 N=128 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry w32x16_k4, split-K 16, raster group 1  [tuned on MI355X (round 4): 11.8 us, 22.7 TFLOP/s two-pass split-K (back to back 9.3 us), verified against the CPU oracle]
+// plan: geometry w32x16_k4, split-K 16, raster group 1  [tuned on MI355X (round 5): 11.8 us, 22.7 TFLOP/s two-pass split-K (back to back 9.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

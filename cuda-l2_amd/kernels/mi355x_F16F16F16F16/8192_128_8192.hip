@@ -1,5 +1,5 @@
 // M=8192 N=128 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 4, K stagger per XCD, raster group 4  [tuned on MI355X (round 4): 40.2 us, 427.1 TFLOP/s two-pass split-K, K stagger per XCD (back to back 38.4 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 4, K stagger per XCD, raster group 4  [tuned on MI355X (round 5): 40.2 us, 427.1 TFLOP/s two-pass split-K, K stagger per XCD (back to back 38.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"

@@ -1,5 +1,5 @@
 // M=16384 N=16384 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 4  [tuned on MI355X (round 4): 1504.4 us, 1461.8 TFLOP/s K stagger per XCD (back to back 1489.3 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 4  [tuned on MI355X (round 5): 1504.4 us, 1461.8 TFLOP/s K stagger per XCD (back to back 1489.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

@@ -1,5 +1,5 @@
 // M=16384 N=256 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 4): 115.7 us, 890.8 TFLOP/s two-pass split-K (back to back 114.5 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 5): 115.7 us, 890.8 TFLOP/s two-pass split-K (back to back 114.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

@@ -1,5 +1,5 @@
 // M=64 N=64 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry w16x16_k4, split-K 16, raster group 1  [tuned on MI355X (round 4): 10.7 us, 12.5 TFLOP/s two-pass split-K (back to back 8.4 us), verified against the CPU oracle]
+// plan: geometry w16x16_k4, split-K 16, raster group 1  [tuned on MI355X (round 5): 10.7 us, 12.5 TFLOP/s two-pass split-K (back to back 8.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"

@@ -122,6 +122,7 @@ def eval_shape(hgemm, mnk: str, args, rng: np.random.Generator) -> dict:
     ours_ms = [x for s in series.values() for x in s["ours_ms"]]
     out = {"mnk": mnk, "acc_precise": args.acc_precise, "mode": args.mode, "rounds": rounds, "warmup_rounds": warm_rounds,
            "wall_s": round(wall, 4), "autotune_find_s": round(t_find, 3), "autotune_ok": auto_ok,
+           "autotune_budget_s": float(os.environ.get("HGEMM_AUTOTUNE_MAX_SECONDS", "30")),
            "summary": summarize_pairs(series, cuda_name),
            "latency_ms": {cuda_name: {"mean": float(np.mean(ours_ms)), "p50": percentile(ours_ms, 50), "p99": percentile(ours_ms, 99)}}}
     for name, s in series.items():
@@ -136,6 +137,10 @@ def eval_shape(hgemm, mnk: str, args, rng: np.random.Generator) -> dict:
         lib = ctypes.CDLL(str(PKG_DIR / "lib" / "libhgemm_mi355x.so"))
         out["hipblaslt_compute16_fallback"] = {"heuristic_tn": lib.hgemm_hipblaslt_compute16_fallback(0, 1),
                                                "autotune_tn": lib.hgemm_hipblaslt_compute16_fallback(1, 1)}
+        # (round 6) the search result came from the on-disk cache of winners (HGEMM_AUTOTUNE_CACHE) / was searched here
+        lib.hgemm_hipblaslt_autotune_best_ms.restype = ctypes.c_double
+        out["autotune"] = {lay: {"from_cache": bool(lib.hgemm_hipblaslt_autotune_from_cache(t)), "candidates": lib.hgemm_hipblaslt_autotune_candidates(t),
+                                 "search_median_ms": lib.hgemm_hipblaslt_autotune_best_ms(t)} for lay, t in (("tn", 1), ("nn", 0))}
     except OSError:
         pass
     return out

@@ -51,9 +51,26 @@ def main(argv=None) -> int:
     ap.add_argument("--require-shipped", action="store_true", help="only touch shapes whose shipped plan was measured in the same run (a run "
                     "that times one family's plans says nothing about a row that ships another family's)")
     ap.add_argument("--report", default="", help="write the list of changed rows (JSON lines)")
+    ap.add_argument("--round", default="", help='provenance label of the regenerated kernel files, e.g. "round 6" (default: taken from the '
+                    "first run file's name, rNN_... -> round NN; ADVICE r5: the label used to be hard-coded)")
+    ap.add_argument("--stability", action="append", default=[], help="a SECOND measurement of the same candidates (another pass / box): a pick is "
+                    "adopted only if it is in this run too, its two times agree within --stability-tol, and it still beats the shipped plan "
+                    "there by --min-gain (VERDICT r5 item 5: 2048x1024x4096 read 26 us in the tune passes and 36 us in the closing run)")
+    ap.add_argument("--stability-tol", type=float, default=0.10)
     ap.add_argument("--exclude", action="append", default=[], help="M_N_K:config:splits -- a candidate not to adopt although it measured fastest "
                     "(e.g. a one-tile-per-CU lock-step plan whose time is known to depend on the box, DESIGN.md section 4.12)")
     a = ap.parse_args(argv)
+    if not a.round:
+        m0 = re.match(r"r(\d+)_", Path(a.runs[0]).name)
+        a.round = f"round {int(m0[1])}" if m0 else "round ?"
+    second = {}   # (mnk, config, splits, group_m) -> us in the stability run(s) (the slowest reading counts)
+    for path in a.stability:
+        for line in open(path):
+            rec = json.loads(line)
+            for c in rec["candidates"]:
+                key = (rec["mnk"], c["config"], int(c["splits"]), int(c["group_m"]))
+                second[key] = max(second.get(key, 0.0), c["us"])
+    unstable = []
     ok = set()
     for line in open(a.verified):
         r = json.loads(line)
@@ -88,6 +105,14 @@ def main(argv=None) -> int:
                 continue
             if ship_us is not None and ship_us < pick["us"] * a.min_gain:
                 continue
+            if a.stability:
+                key = (mnk, pick["config"], int(pick["splits"]), int(pick["group_m"]))
+                us2 = second.get(key)
+                ship2 = second.get((mnk,) + shipped)
+                if us2 is None or abs(us2 - pick["us"]) > a.stability_tol * min(us2, pick["us"]) or (ship2 is not None and ship2 < us2 * a.min_gain):
+                    unstable.append({"mnk": mnk, "config": pick["config"], "splits": int(pick["splits"]), "us": pick["us"], "us_second": us2,
+                                     "shipped_us_second": ship2})
+                    continue
             mm, nn, kk = map(int, mnk.split("_"))
             iso = pick.get("isolated_us", pick["us"])
             note = f"{iso:.1f} us, {2.0 * mm * nn * kk / iso * 1e-6:.1f} TFLOP/s{form_text(int(pick['splits']))}"
@@ -100,7 +125,7 @@ def main(argv=None) -> int:
             if not a.no_shape_files:
                 for acc in ACC_DIRS:
                     write_shape_file(mnk, acc, plan=(pick["config"], int(pick["splits"]), int(pick["group_m"])),
-                                     source=f"tuned on MI355X (round 4): {note}, verified against the CPU oracle")
+                                     source=f"tuned on MI355X ({a.round}): {note}, verified against the CPU oracle")
     head = [ln for ln in lines if not ROW.match(ln)]
     text = "\n".join(lines) + "\n"
     text = text.replace("split-K (| 0x10000 = single-launch form, | 0x20000 = non-temporal C stores), raster group}",
@@ -110,6 +135,10 @@ def main(argv=None) -> int:
         with open(a.report, "w") as f:
             for c in changed:
                 f.write(json.dumps(c) + "\n")
+    if a.stability:
+        print(f"stability gate: {len(unstable)} picks rejected (absent from / unstable in / not winning in the second measurement)")
+        for u in unstable[:40]:
+            print("  rejected", json.dumps(u))
     print(f"{len(changed)} rows changed of {len(index)}; header lines {len(head)}")
     return 0
 

@@ -147,10 +147,18 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m,
  * With HGEMM_MI355X_INSITU=1 in the environment, or after hgemm_mi355x_set_insitu(1) (returns the previous setting; 0 also
  * forgets every recorded choice), the FIRST call of hgemm_mi355x_fp32 / _fp16 for a shape times up to three oracle-verified
  * plans -- the table's and its alternates (hgemm_mi355x_insitu_candidates lists them, the table's plan first) -- on the call's
- * own operands and stream, keeps the fastest for the process (an alternate must win by 3 %) and runs it; that call
+ * own operands and stream (interleaved rounds), keeps the fastest for the (process, device) (an alternate must win by 3 %) and runs it; that call
  * synchronises the stream, so it belongs in a warm-up phase.  Later calls, and calls on a capturing stream, time nothing.
  * hgemm_mi355x_insitu_choice returns 1 and the recorded plan once a shape has been measured. */
 int hgemm_mi355x_set_insitu(int enable);
+/* 1 when first-use selection is on (environment or hgemm_mi355x_set_insitu).  The per-shape kernel files
+ * (csrc/hgemm_shape_entry.hpp) ask this before they launch their pinned plan: with the selection on they hand the call to
+ * hgemm_mi355x_fp32 / _fp16 instead, so that `HGEMM_MI355X_INSITU=1 ./eval_one_file.sh ...` (or `--insitu`) measures on the
+ * harness path -- where the reference's first-call autotune runs (kernels/h100_F32F16F16F32/64_4096_64.cu:702-721).
+ * Choices are kept per (device, shape).  With the selection on, N(0,1) results may differ in their last bits from run to run and box
+ * to box: a split-K / K-stagger alternate adds a tile's K stages up in another (fixed, deterministic per plan) order; 0/1 inputs
+ * stay exact whatever is chosen. */
+int hgemm_mi355x_insitu_enabled(void);
 int hgemm_mi355x_insitu_candidates(int M, int N, int K, int config_id[3], int splits[3], int group_m[3]);
 int hgemm_mi355x_insitu_choice(int M, int N, int K, int* config_id, int* splits, int* group_m);
 
@@ -255,6 +263,18 @@ int hgemm_hipblaslt_autotune_find_best_nn(int M, int N, int K, int acc);
 int hgemm_hipblaslt_autotune_find_best_tn(int M, int N, int K, int acc);
 int hgemm_hipblaslt_autotune_nn(const void* a, const void* b, void* c, int M, int N, int K, int acc, void* stream);
 int hgemm_hipblaslt_autotune_tn(const void* a, const void* b_col_major, void* c, int M, int N, int K, int acc, void* stream);
+/* On-disk cache of the search results (round 6).  The reference repeats the search in every benchmarking process
+ * (benchmarking_offline.py:71-84: find_best_algo_* right after the handles are created), 7 + 1 processes per shape; over a
+ * 1000-shape grid x two accumulate trees x two modes that is the same search eight thousand times.  With a cache file -- the
+ * environment's HGEMM_AUTOTUNE_CACHE, or hgemm_hipblaslt_autotune_set_cache(path) (NULL / "" = none) -- find_best_* first looks the
+ * problem (layout, M, N, K, compute type) up: a record searched with at least the current HGEMM_AUTOTUNE_MAX_SECONDS whose
+ * hipBLASLt solution index the running library accepts for the problem is taken as the winner without timing anything;
+ * otherwise the search runs and appends its winner (text, one line per problem: tn M N K compute16 algo_index best_ms candidates
+ * warm timed budget_s solution_name).  hgemm_hipblaslt_autotune_from_cache(tn): 1 when the last find_best of that layout was a
+ * cache hit; _cache_stats: records held, hits / misses of this process. */
+int hgemm_hipblaslt_autotune_set_cache(const char* path);
+int hgemm_hipblaslt_autotune_from_cache(int tn);
+int hgemm_hipblaslt_autotune_cache_stats(int* hits, int* misses);
 /* Introspection for reports: candidates tried / median ms of the winner (nn = 0, tn = 1). */
 int hgemm_hipblaslt_autotune_candidates(int tn);
 double hgemm_hipblaslt_autotune_best_ms(int tn);

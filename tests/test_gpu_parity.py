@@ -881,7 +881,8 @@ def test_first_use_selection_picks_a_listed_plan_and_stays_exact(g, oracle):
     import ctypes
 
     L = g.lib()
-    assert L.hgemm_mi355x_set_insitu(1) == 0
+    L.hgemm_mi355x_set_insitu(0)                   # whatever HGEMM_MI355X_INSITU says: start from "off, nothing recorded"
+    assert L.hgemm_mi355x_set_insitu(1) == 0 and L.hgemm_mi355x_insitu_enabled() == 1
     try:
         for m, n, k in ((2048, 2048, 2048), (8192, 2048, 256), (1000, 520, 200), (256, 16384, 4096)):
             rng = np.random.default_rng(m + 7 * n + k)

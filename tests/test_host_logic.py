@@ -744,7 +744,8 @@ def test_first_use_selection_is_off_by_default_and_lists_launchable_candidates(l
     no duplicates, every geometry accepts the K, alternates of grid shapes come from the generated table whose rows name
     existing geometries."""
     lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
-    assert lib.hgemm_mi355x_set_insitu(0) == 0          # environment not set in the test run: it was off
+    lib.hgemm_mi355x_set_insitu(0)                      # (whatever HGEMM_MI355X_INSITU says: off, nothing recorded)
+    assert lib.hgemm_mi355x_insitu_enabled() == 0 and lib.hgemm_mi355x_set_insitu(0) == 0
     cfg, sp, gm = (ctypes.c_int * 3)(), (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
     c0, s0, g0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     for mnk in ((4096, 4096, 4096), (16384, 256, 16384), (8192, 8192, 256), (64, 4096, 64), (1000, 520, 200), (4000, 4000, 4000), (65, 30, 100)):
@@ -762,3 +763,26 @@ def test_first_use_selection_is_off_by_default_and_lists_launchable_candidates(l
         assert lib.hgemm_mi355x_config_by_name(name.encode()) >= 0, name
         per_shape.setdefault((m, n_, k), []).append((name, s, g))
     assert all(len(v) <= 2 and len(set(v)) == len(v) for v in per_shape.values())
+
+
+def test_autotune_cache_file_is_read_and_counts_records(lib, tmp_path):
+    """Round 6: the on-disk cache of hipBLASLt autotune winners (include/hgemm_mi355x.h: hgemm_hipblaslt_autotune_set_cache).  Without
+    a GPU only the file handling can run: comment and malformed lines are skipped, records are counted, an unset / missing file is
+    an empty cache, and find_best_* without its init still answers NOT_READY (it never touches the cache then)."""
+    f = tmp_path / "cache.txt"
+    f.write_text("# header\n"
+                 "1 64 4096 64 0 73412 0.004321 37 50 100 1.000 Cijk_Alik_Bljk_HHS_BH_MT32x32x64\n"
+                 "0 64 4096 64 0 73999 0.005000 37 50 100 1.000 -\n"
+                 "garbage line\n"
+                 "1 512 4096 4096 0 12 0.027 100 12 25 1.000\n")          # (no solution name: still a record)
+    lib.hgemm_hipblaslt_autotune_set_cache.argtypes = [ctypes.c_char_p]
+    h, m = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.hgemm_hipblaslt_autotune_set_cache(str(f).encode()) == 0
+    assert lib.hgemm_hipblaslt_autotune_cache_stats(ctypes.byref(h), ctypes.byref(m)) == 3
+    assert (h.value, m.value) == (0, 0)
+    assert lib.hgemm_hipblaslt_autotune_set_cache(str(tmp_path / "missing.txt").encode()) == 0
+    assert lib.hgemm_hipblaslt_autotune_cache_stats(None, None) == 0
+    assert lib.hgemm_hipblaslt_autotune_set_cache(None) == 0
+    assert lib.hgemm_hipblaslt_autotune_cache_stats(None, None) == 0
+    assert lib.hgemm_hipblaslt_autotune_from_cache(1) == 0
+    assert lib.hgemm_hipblaslt_autotune_find_best_tn(64, 4096, 64, 0) == -5     # HGEMM_ERR_NOT_READY: no init, no GPU
