@@ -547,6 +547,55 @@ __device__ __forceinline__ bool fused_publish_and_vote(const GemmArgs& g, int ti
   __syncthreads();
   return *lds_flag != 0u;
 }
+
+// The last arriver's combine: out[x] = slab(0)[x] + slab(1)[x] + ... + slab(splits - 1)[x], added IN THAT ORDER (so the bits do not
+// depend on who arrives last), for the NQ quads quad_of(0 .. NQ-1) of this thread.
+// Round 6: up to UMAX slabs' loads are in flight behind ONE wait.  The loop this replaces loaded a split's quads,
+// waited for them, added them, and only then asked for the next split's -- `splits` dependent round trips to the memory side of the
+// fabric (the slabs are sc1 / write-through data: every load misses the XCD's L2 by design), 16 of them for a 16-way split of a
+// 64 x 64 output.  That serial walk, not the arrival protocol, is why the single-launch form lost to the two-pass form (a second
+// dispatch, ~2.5 us back to back) on all but the smallest splits; the reference's one-launch split-K meets in L2 atomics
+// (kernels/a100_F32F16F16F32/64_256_16384.cu:24-31,149-152) and pays no such walk.  With the loads batched the combine is
+// ceil(splits / UMAX) round trips.  Slab 0 initialises (no "+ 0.0": a sum of -0.0 partials stays -0.0 as before).
+template <int THREADS, int NQ, int UMAX, class QuadOf>
+__device__ __forceinline__ void fused_combine(__amdgpu_buffer_rsrc_t rsP, int splits, int tiles, int tile, int slab_elems, int tid,
+                                              QuadOf quad_of, f32x4 (&out)[NQ]) {
+  static_assert(UMAX == 1 || UMAX == 2 || UMAX == 4 || UMAX == 8 || UMAX == 16 || UMAX == 32, "batch depth");
+  int s = 0;
+  auto batch = [&](auto u_tag, auto first_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    f32x4 v[U][NQ];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[u][q] = fused_load(rsP, fused_off<THREADS>((s + u) * tiles + tile, slab_elems, quad_of(q), tid));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) out[q] = (FIRST && u == 0) ? v[u][q] : out[q] + v[u][q];
+    s += U;
+  };
+  using std::integral_constant;
+  using T = std::true_type;
+  using F = std::false_type;
+  // first batch: the deepest that fits (splits >= 1 always)
+  if (UMAX >= 32 && splits >= 32) batch(integral_constant<int, (UMAX >= 32 ? 32 : 1)>{}, T{});
+  else if (UMAX >= 16 && splits >= 16) batch(integral_constant<int, (UMAX >= 16 ? 16 : 1)>{}, T{});
+  else if (UMAX >= 8 && splits >= 8) batch(integral_constant<int, (UMAX >= 8 ? 8 : 1)>{}, T{});
+  else if (UMAX >= 4 && splits >= 4) batch(integral_constant<int, (UMAX >= 4 ? 4 : 1)>{}, T{});
+  else if (UMAX >= 2 && splits >= 2) batch(integral_constant<int, (UMAX >= 2 ? 2 : 1)>{}, T{});
+  else batch(integral_constant<int, 1>{}, T{});
+  if constexpr (UMAX >= 32) { while (s + 32 <= splits) batch(integral_constant<int, 32>{}, F{}); }
+  if constexpr (UMAX >= 16) { while (s + 16 <= splits) batch(integral_constant<int, 16>{}, F{}); }
+  if constexpr (UMAX >= 8) { while (s + 8 <= splits) batch(integral_constant<int, 8>{}, F{}); }
+  if constexpr (UMAX >= 4) { while (s + 4 <= splits) batch(integral_constant<int, 4>{}, F{}); }
+  if constexpr (UMAX >= 2) { while (s + 2 <= splits) batch(integral_constant<int, 2>{}, F{}); }
+  while (s < splits) batch(integral_constant<int, 1>{}, F{});
+}
+// batch depth for a thread that owns NQ quads: at most 32 sixteen-byte loads (128 registers) in flight
+template <int NQ>
+struct FusedBatch { static constexpr int U = NQ <= 1 ? 32 : NQ <= 2 ? 16 : NQ <= 4 ? 8 : NQ <= 8 ? 4 : NQ <= 16 ? 2 : 1; };
 #endif  // __HIP_DEVICE_COMPILE__
 
 // The buffer-resource builtins only exist in the device pass; the host pass just needs the
@@ -811,18 +860,18 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_kernel(const GemmArgs g
         }
     if (!fused_publish_and_vote(g, tc.tile, (volatile unsigned*)smem, tid)) return;
     // last arriver: slabs of this tile are item = s * tiles + tile, s = 0 .. splits-1, added in that order
-    const int tiles = g.tiles_m * g.tiles_n;
-    for (int sidx = 0; sidx < g.splits; ++sidx) {
+    {
+      constexpr int NQT = FM * FN * NQ;
+      f32x4 sum[NQT];
+      fused_combine<CFG::THREADS, NQT, FusedBatch<NQT>::U>(rsP, g.splits, g.tiles_m * g.tiles_n, tc.tile, SLAB, tid, [](int x) { return x; }, sum);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, SLAB, (i * FN + j) * NQ + q, tid));
+          for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = (sidx == 0) ? v[e] : acc[i][j][q * 4 + e] + v[e];
-          }
+            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = sum[(i * FN + j) * NQ + q][e];
     }
     store_tile<MI, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
   } else {

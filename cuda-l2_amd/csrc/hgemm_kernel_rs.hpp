@@ -72,18 +72,18 @@ __device__ __forceinline__ void classic_epilogue(const GemmArgs& g, const TileCo
         }
     if (!fused_publish_and_vote(g, tc.tile, (volatile unsigned*)smem, tid)) return;
     // last arriver: slabs of this tile are item = s * tiles + tile, s = 0 .. splits-1, added in that order
-    const int tiles = g.tiles_m * g.tiles_n;
-    for (int sidx = 0; sidx < g.splits; ++sidx) {
+    {
+      constexpr int NQT = FM * FN * NQ;
+      f32x4 sum[NQT];
+      fused_combine<CFG::THREADS, NQT, FusedBatch<NQT>::U>(rsP, g.splits, g.tiles_m * g.tiles_n, tc.tile, SLAB, tid, [](int x) { return x; }, sum);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, SLAB, (i * FN + j) * NQ + q, tid));
+          for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = (sidx == 0) ? v[e] : acc[i][j][q * 4 + e] + v[e];
-          }
+            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = sum[(i * FN + j) * NQ + q][e];
     }
     store_tile<MI, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
   } else {

@@ -541,6 +541,26 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       if (hw & 1u) __builtin_amdgcn_s_setprio(2);
     }
+    // flags bit 6 (HGEMM_PLAN_CU_PHASE, round 6), two-resident members: the phase offset INSIDE a CU.  The two workgroups of a CU
+    // start together and do the same work, so they reach their epilogues together: two waves per SIMD, yet the matrix pipe idles
+    // while both store and the store path idles while both multiply ("two workgroups per CU do NOT overlap
+    // one's epilogue with the other's K loop").  The phase groups of bit 3 / 5 are taken from the workgroup's index inside its XCD,
+    // which gives the two residents of a CU the SAME group.  Here the workgroup whose waves sit in the odd hardware wave slots
+    // enters its walk half an item period late -- the period of a workgroup that shares its CU: both K loops back to back plus an
+    // epilogue -- so that one resident's epilogue runs under the other's K loop: the ping-pong of the reference's warp-specialised
+    // H100 kernels (KernelTmaWarpSpecializedPingpong, kernels/h100_F32F16F16F32/1024_16384_128.cu:157) with two 4-wave workgroups
+    // as the two halves.  Walks of several items only (a single item would just finish half a period later).
+    if ((g.flags & 64) && walk.count > 1) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      if (hw & 1u) {
+        const int nk0 = g.k_chunk / (BK * CFG::KT);
+        const int kloop = nk0 * 2 * CFG::T * 16;                       // MFMA cycles of one item's K loop (shader cycles, roughly)
+        const int half = kloop + CFG::BM * CFG::BN / 24;               // half of (two K loops + one epilogue)
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < half; c += 1024) __builtin_amdgcn_s_sleep(16);
+      }
+    }
   }
 
   // fragment lane mapping (hgemm_kernel_sp.hpp): MI = 16: row lane & 15, 16-B chunk 4h + (lane >> 4);
@@ -725,17 +745,67 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       if (fused_publish_and_vote(g, tc.tile, (volatile unsigned*)(smem + CFG::LDS_BYTES), tid)) {
         const int tiles = g.tiles_m * g.tiles_n;
         if constexpr (MI == 16) {
-#pragma unroll 1
-          for (int i = 0; i < FM; ++i) {
-            f32x4 row[FN];
-            for (int sidx = 0; sidx < g.splits; ++sidx) {
+          // Round 6: the combine used to be FM x splits dependent round trips to the memory side of the fabric (a fragment row's
+          // quads of ONE slab, wait, add, next slab; next row) -- 8 of them for the 2-way split of 512 x 4096 x 4096 on q128x128,
+          // on top of an epilogue that no MFMA covers.  Now the first UQ slabs of a fragment row are requested together (up to 8 loads)
+          // and the NEXT row's go out before this row is added up and stored: one round trip + FM issue slots for splits <= UQ.
+          // Slabs are added in split order as before (slab 0 initialises); loads of u >= splits re-read the last slab and their sum is
+          // discarded by a select (no branch: the compiler's waits stay counted).
+          // (register budget: this row's UQ x FN quads + the next row's must fit beside the fragment sets without the compiler
+          // reaching for the AGPRs that hold the accumulators -- tests/test_build_audit.py; at most 8-12 quads per batch)
+          constexpr int UQ = FN <= 2 ? 4 : 2;
+          if constexpr (FN < 8 && FM * FN <= 32) {
+            const int S = g.splits;
+            auto issue = [&](int i, f32x4 (&buf)[UQ][FN]) __attribute__((always_inline)) {
 #pragma unroll
-              for (int j = 0; j < FN; ++j) {
-                const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
-                row[j] = (sidx == 0) ? v : row[j] + v;
+              for (int u = 0; u < UQ; ++u) {
+                const int su = min(u, S - 1);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) buf[u][j] = fused_load(rsP, fused_off<CFG::THREADS>(su * tiles + tc.tile, BM * BN, i * FN + j, tid));
               }
+            };
+            f32x4 nxt[UQ][FN];
+            issue(0, nxt);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+              f32x4 cur[UQ][FN];
+#pragma unroll
+              for (int u = 0; u < UQ; ++u)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) cur[u][j] = nxt[u][j];
+              if (i + 1 < FM) issue(i + 1, nxt);
+              f32x4 row[FN];
+#pragma unroll
+              for (int j = 0; j < FN; ++j) row[j] = cur[0][j];
+#pragma unroll
+              for (int u = 1; u < UQ; ++u)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                  const f32x4 t = row[j] + cur[u][j];
+                  row[j] = (u < S) ? t : row[j];
+                }
+              for (int sidx = UQ; sidx < S; ++sidx) {   // deeper splits than UQ (rare on these tiles): one slab at a time, as before
+#pragma unroll
+                for (int j = 0; j < FN; ++j) row[j] += fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
+              }
+              store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
             }
-            store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
+          } else {
+            // the members with more than 128 accumulator registers (256 x 256, 256 x 192, 192 x 256, 128 x 256) have no room for a
+            // second batch of quads in flight in their fused + K-tail variants (the compiler would park VGPRs in the accumulators'
+            // AGPRs: tests/test_build_audit.py): they keep the round-2 walk, one slab of one fragment row per round trip
+#pragma unroll 1
+            for (int i = 0; i < FM; ++i) {
+              f32x4 row[FN];
+              for (int sidx = 0; sidx < g.splits; ++sidx) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                  const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, BM * BN, i * FN + j, tid));
+                  row[j] = (sidx == 0) ? v : row[j] + v;
+                }
+              }
+              store_tile_row<16, FN, CFG::TM, CFG::TN, false, -1>(g, tc, wave_m, wave_n, lane, i, row);
+            }
           }
         } else {
 #pragma unroll 1

@@ -119,15 +119,13 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_wd_kernel(const GemmArg
 #pragma unroll
         for (int j = 0; j < FN; ++j) fused_store(rsP, fused_off<CFG::THREADS>(tc.item, SLAB, i * FN + j, tid), acc[i][j]);
       if (!fused_publish_and_vote(g, tc.tile, (volatile unsigned*)smem, tid)) return;
-      const int tiles = g.tiles_m * g.tiles_n;
-      for (int sidx = 0; sidx < g.splits; ++sidx) {
+      {   // the slabs in split order, up to 8 of them in flight per round trip (fused_combine, hgemm_kernel.hpp)
+        f32x4 sum[NQUAD];
+        fused_combine<CFG::THREADS, NQUAD, FusedBatch<NQUAD>::U>(rsP, g.splits, g.tiles_m * g.tiles_n, tc.tile, SLAB, tid, [](int x) { return x; }, sum);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            const f32x4 v = fused_load(rsP, fused_off<CFG::THREADS>(sidx * tiles + tc.tile, SLAB, i * FN + j, tid));
-            acc[i][j] = (sidx == 0) ? v : acc[i][j] + v;
-          }
+          for (int j = 0; j < FN; ++j) acc[i][j] = sum[i * FN + j];
       }
       store_tile<16, FM, FN, CFG::TM, CFG::TN, false>(g, tc, wave_m, wave_n, lane, acc);
     } else {
@@ -165,15 +163,15 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_wd_kernel(const GemmArg
       }
       // (the vote word sits behind the partials; its own barriers order it against the reads above)
       if (!fused_publish_and_vote(g, tc.tile, flag, tid)) return;
-      const int tiles = g.tiles_m * g.tiles_n;
+      // (quad x of lane l sits at (x * 64 + l) * 4 floats of a slab: fused_off's layout with a "workgroup" of 64 threads)
 #pragma unroll
       for (int q = 0; q < MYQ; ++q) {
         const int x = wave + q * KW;
-        if (x < NQUAD)
-          for (int sidx = 0; sidx < g.splits; ++sidx) {
-            const f32x4 v = fused_load(rsP, ((uint32_t)(sidx * tiles + tc.tile) * SLAB + (uint32_t)(x * 64 + lane) * 4u) * 4u);
-            sum[q] = (sidx == 0) ? v : sum[q] + v;
-          }
+        if (x < NQUAD) {
+          f32x4 one[1];
+          fused_combine<64, 1, 32>(rsP, g.splits, g.tiles_m * g.tiles_n, tc.tile, SLAB, lane, [x](int) { return x; }, one);
+          sum[q] = one[0];
+        }
       }
       store_c = true;
     }

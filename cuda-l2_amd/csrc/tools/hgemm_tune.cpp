@@ -199,6 +199,68 @@ static bool g_rank_both = false;
 static bool g_stream_report = false;   // tune --plan-only --baselines --stream
 static bool g_try_nt = false;   // tune --nt: streaming C stores for the winner, judged back to back (HGEMM_PLAN_NT_STORE)
 
+// tune --plan-only --baselines --interleave (round 6): the report's contenders -- our plan, rocBLAS nn / tn,
+// hipBLASLt-heuristic nn / tn, hipBLASLt-autotune nn / tn -- are timed in INTERLEAVED rounds with one warm history instead of one
+// after the other: every round launches every contender once (isolated clock: one event pair around one launch, a sync behind it)
+// resp. runs one back-to-back box of each (stream clock), and the order rotates from round to round (--reverse: the opposite
+// rotation, for the order-reversal test).  The autotune search runs BEFORE any timing (with HGEMM_AUTOTUNE_CACHE it times nothing)
+// and a warm round of every contender separates it from the first sample.  Round 5's report timed contenders sequentially, ours
+// first and right behind the previous shape's two seconds of autotune launches: the device-bound decades moved +-5 % with the order
+// (DESIGN.md section 6.7).  Same record keys as the sequential report, plus "protocol".
+static bool g_interleave = false;
+static bool g_reverse = false;
+#include <functional>
+struct Contender {
+  const char* key;                          // JSON key stem
+  std::function<int(Buffers&)> launch;
+  std::vector<float> iso;                   // one sample per round, us
+  std::vector<float> box;                   // one back-to-back box per stream round, us per call
+  bool ok = true;
+  double iso_us() const { return ok && !iso.empty() ? median(iso) : -1.0; }
+  double box_us() const { return ok && !box.empty() ? median(box) : -1.0; }
+};
+static void time_interleaved(std::vector<Contender>& cs, std::vector<Buffers>& sets, int rounds, int stream_rounds, double box_s, double est_us,
+                             hipEvent_t e0, hipEvent_t e1) {
+  const int n = (int)cs.size();
+  auto order = [&](int round, int i) { return g_reverse ? ((n - 1 - i) + n - round % n) % n : (i + round) % n; };
+  // warm round: two launches of everybody (first-call setup of the vendor libraries, clocks up), untimed
+  for (int w = 0; w < 2; ++w)
+    for (int i = 0; i < n; ++i) {
+      Contender& c = cs[order(w, i)];
+      if (c.ok && c.launch(sets[w % sets.size()]) != HGEMM_OK) c.ok = false;
+    }
+  HIP_OK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r)
+    for (int i = 0; i < n; ++i) {
+      Contender& c = cs[order(r, i)];
+      if (!c.ok) continue;
+      if (g_cooldown_ms > 0) { HIP_OK(hipDeviceSynchronize()); std::this_thread::sleep_for(std::chrono::milliseconds(g_cooldown_ms)); }
+      Buffers& s = sets[(r * n + i) % sets.size()];
+      HIP_OK(hipEventRecord(e0, nullptr));
+      if (c.launch(s) != HGEMM_OK) { c.ok = false; HIP_OK(hipDeviceSynchronize()); continue; }
+      HIP_OK(hipEventRecord(e1, nullptr));
+      HIP_OK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      c.iso.push_back(ms * 1000.f);
+    }
+  if (stream_rounds <= 0) return;
+  const int reps = (int)std::max(8.0, std::min(20000.0, box_s * 1e6 / std::max(1.0, est_us)));
+  for (int r = 0; r < stream_rounds; ++r)
+    for (int i = 0; i < n; ++i) {
+      Contender& c = cs[order(r, i)];
+      if (!c.ok) continue;
+      // (no per-box warm-up: the previous contender's box is this one's warm history -- the same for everybody over the rotation)
+      HIP_OK(hipEventRecord(e0, nullptr));
+      for (int k = 0; k < reps; ++k) (void)c.launch(sets[k % sets.size()]);
+      HIP_OK(hipEventRecord(e1, nullptr));
+      HIP_OK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      c.box.push_back((float)(ms * 1000.0 / reps));
+    }
+}
+
 static int default_group(int cfg, const Shape& sh) { return hgemm_mi355x_default_group(cfg, sh.M, sh.N); }
 
 static std::vector<std::string> g_config_filter;  // --configs a,b,c: only these geometries are candidates
@@ -337,6 +399,11 @@ static int cmd_check(const std::vector<Shape>& shapes) {
       const char fam = c >= 0 ? cname[0] : ' ';
       std::vector<int> forms = {1, 2, 3, 8, 2 | HGEMM_SPLITK_FUSED, 8 | HGEMM_SPLITK_FUSED, HGEMM_PLAN_STREAMK, 5 | HGEMM_PLAN_STREAMK,
                                 37 | HGEMM_PLAN_STREAMK, 300 | HGEMM_PLAN_STREAMK};
+      // round 6: the last arriver of a single-launch split-K adds the slabs in batches of 32 / 16 / 8 / 4 / 2 / 1 (fused_combine,
+      // hgemm_kernel.hpp; family q: 2 or 4 slabs ahead + a tail loop) -- split counts that walk every batch depth and remainder
+      // (on the shapes with K >= 2048 only: that is where 13 .. 48 splits of >= one stage exist, and it keeps the check's run count down)
+      if (sh.K >= 2048)
+        for (int f : {3, 5, 7, 13, 16, 21, 32, 37, 48}) forms.push_back(f | HGEMM_SPLITK_FUSED);
       if (fam == 'r')   // family r's plan flags (K stagger per XCD, non-temporal loads of the streamed operand), alone and combined
         forms.insert(forms.end(), {1 | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS, 2 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_RS_XCD_STAGGER,
                                    3 | HGEMM_PLAN_RS_NT_LOADS, 37 | HGEMM_PLAN_STREAMK | HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS});
@@ -345,7 +412,9 @@ static int cmd_check(const std::vector<Shape>& shapes) {
                                    4 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_XCD_STAGGER,
                                    // the walk's phase flags (prologue only: a sleep / a priority): alone, together, with a stagger
                                    1 | HGEMM_PLAN_PHASE_OFFSET, 1 | HGEMM_PLAN_PHASE_OFFSET4, 1 | HGEMM_PLAN_PHASE_OFFSET8, 1 | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_NT_STORE,
-                                   2 | HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_XCD_STAGGER});
+                                   2 | HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_XCD_STAGGER,
+                                   // round 6: the phase offset inside a CU (two-resident members; a prologue sleep like the others)
+                                   1 | HGEMM_PLAN_CU_PHASE, 1 | HGEMM_PLAN_CU_PHASE | HGEMM_PLAN_NT_STORE, 2 | HGEMM_PLAN_CU_PHASE | HGEMM_PLAN_XCD_STAGGER});
       for (int splits : forms) {
         const bool sk = (splits & HGEMM_PLAN_STREAMK) != 0;
         const int sp = sk ? 2 : (splits & HGEMM_SPLITK_MASK);   // (sp > 1: run twice, one raster group)
@@ -393,7 +462,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     if (g_config_filter.empty() || std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) != g_config_filter.end())
       printf(" %s", cname);
   }
-  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger 1|phase-offset 1|phase-offset4 1|phase-offset8 1|wave-priority|nt-store 2|phase-offset|wave-priority|xcd-stagger, raster groups 1 4\n");
+  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused 3|fused 5|fused 7|fused 13|fused 16|fused 21|fused 32|fused 37|fused 48|fused (3|fused .. 48|fused: K >= 2048) streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger 1|phase-offset 1|phase-offset4 1|phase-offset8 1|wave-priority|nt-store 2|phase-offset|wave-priority|xcd-stagger 1|cu-phase 1|cu-phase|nt-store 2|cu-phase|xcd-stagger, raster groups 1 4\n");
   printf("check: %d runs, %d failures (bit-exact against the exact integer result of 0/1 inputs)\n", runs, failures);
   return failures ? 1 : 0;
 }
@@ -540,7 +609,46 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       }
     }
     double rb_nn = -1, rb_tn = -1, lt_nn = -1, lt_tn = -1;
-    if (baselines) {
+    double st_ours = -1, st_lt_nn = -1, st_lt_tn = -1;
+    double at_nn = -1, at_tn = -1, st_at_nn = -1, st_at_tn = -1;
+    int at_cand_nn = 0, at_cand_tn = 0;
+    int at_cached[2] = {0, 0};
+    const bool interleaved = baselines && g_plan_only && g_interleave;
+    int il_rounds = 0, il_stream_rounds = 0;
+    if (interleaved) {
+      bool have_at_nn = false, have_at_tn = false;
+      if (autotune) {   // the search first: nothing of it may sit between two timed samples
+        have_at_nn = hgemm_hipblaslt_autotune_find_best_nn(sh.M, sh.N, sh.K, 0) == HGEMM_OK;
+        if (have_at_nn) { at_cand_nn = hgemm_hipblaslt_autotune_candidates(0); at_cached[0] = hgemm_hipblaslt_autotune_from_cache(0); }
+        have_at_tn = hgemm_hipblaslt_autotune_find_best_tn(sh.M, sh.N, sh.K, 0) == HGEMM_OK;
+        if (have_at_tn) { at_cand_tn = hgemm_hipblaslt_autotune_candidates(1); at_cached[1] = hgemm_hipblaslt_autotune_from_cache(1); }
+      }
+      const Plan p = res[0].p;
+      std::vector<Contender> cs;
+      cs.push_back({"ours", [&, p](Buffers& b) { return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, b.a, b.b, b.bt, b.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr); }});
+      cs.push_back({"rocblas_nn", [&](Buffers& b) { return hgemm_rocblas_nn(b.a, b.b, b.c, sh.M, sh.N, sh.K, 0, nullptr); }});
+      cs.push_back({"rocblas_tn", [&](Buffers& b) { return hgemm_rocblas_tn(b.a, b.bt, b.c, sh.M, sh.N, sh.K, 0, nullptr); }});
+      cs.push_back({"heur_nn", [&](Buffers& b) { return hgemm_hipblaslt_heuristic_nn(b.a, b.b, b.c, sh.M, sh.N, sh.K, 0, nullptr); }});
+      cs.push_back({"heur_tn", [&](Buffers& b) { return hgemm_hipblaslt_heuristic_tn(b.a, b.bt, b.c, sh.M, sh.N, sh.K, 0, nullptr); }});
+      if (have_at_nn) cs.push_back({"auto_nn", [&](Buffers& b) { return hgemm_hipblaslt_autotune_nn(b.a, b.b, b.c, sh.M, sh.N, sh.K, 0, nullptr); }});
+      if (have_at_tn) cs.push_back({"auto_tn", [&](Buffers& b) { return hgemm_hipblaslt_autotune_tn(b.a, b.bt, b.c, sh.M, sh.N, sh.K, 0, nullptr); }});
+      il_rounds = flops > 1.5e12 ? 3 : std::max(5, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
+      il_stream_rounds = g_stream_report ? 3 : 0;
+      const double box = g_stream_box_s > 0 ? g_stream_box_s : (flops > 1.5e12 ? 0.012 : 0.008);
+      time_interleaved(cs, sets, il_rounds, il_stream_rounds, box, res[0].us, e0, e1);
+      for (const Contender& c : cs) {
+        const std::string k = c.key;
+        const double iso = c.iso_us(), bx = c.box_us();
+        if (k == "ours") { if (iso > 0) { res[0].us = iso; } st_ours = bx; }
+        else if (k == "rocblas_nn") rb_nn = iso;
+        else if (k == "rocblas_tn") rb_tn = iso;
+        else if (k == "heur_nn") { lt_nn = iso; st_lt_nn = bx; }
+        else if (k == "heur_tn") { lt_tn = iso; st_lt_tn = bx; }
+        else if (k == "auto_nn") { at_nn = iso; st_at_nn = bx; }
+        else if (k == "auto_tn") { at_tn = iso; st_at_tn = bx; }
+      }
+    }
+    if (baselines && !interleaved) {
       const int reps = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
       rb_nn = time_us([&](Buffers& s) { return hgemm_rocblas_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
       rb_tn = time_us([&](Buffers& s) { return hgemm_rocblas_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, 2, reps, e0, e1);
@@ -549,8 +657,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
     }
     // tune --plan-only --baselines --stream: the same comparison back to back (what a model runs: launches queue behind each
     // other, the end-of-kernel release and the clocks of a busy device are part of the figure), short boxes
-    double st_ours = -1, st_lt_nn = -1, st_lt_tn = -1;
-    if (baselines && g_stream_report) {
+    if (baselines && g_stream_report && !interleaved) {
       const double box = g_stream_box_s > 0 ? g_stream_box_s : (flops > 1.5e12 ? 0.012 : 0.008);
       const Plan p = res[0].p;
       st_ours = stream_us([&](Buffers& s) { return hgemm_mi355x_launch(p.cfg, p.splits, p.group_m, s.a, s.b, s.bt, s.c, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nullptr); },
@@ -558,9 +665,7 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       st_lt_tn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_tn(s.a, s.bt, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, lt_tn);
       st_lt_nn = stream_us([&](Buffers& s) { return hgemm_hipblaslt_heuristic_nn(s.a, s.b, s.c, sh.M, sh.N, sh.K, 0, nullptr); }, sets, box, e0, e1, lt_nn);
     }
-    double at_nn = -1, at_tn = -1, st_at_nn = -1, st_at_tn = -1;
-    int at_cand_nn = 0, at_cand_tn = 0;
-    if (baselines && autotune) {
+    if (baselines && autotune && !interleaved) {
       // the reference's strongest baseline (cublaslt_auto_tuning): per-shape search over the heuristic
       // candidates, time-boxed by HGEMM_AUTOTUNE_MAX_SECONDS, then timed like every other entry
       const int reps = flops > 1.5e12 ? 2 : std::max(3, (int)std::min(30.0, 20000.0 / std::max(2.0, res[0].us)));
@@ -592,6 +697,9 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       fprintf(out, ", \"hipblaslt_auto_nn_us\": %.3f, \"hipblaslt_auto_tn_us\": %.3f, \"hipblaslt_auto_candidates\": [%d, %d]", at_nn, at_tn,
               at_cand_nn, at_cand_tn);
     if (st_at_nn > 0 || st_at_tn > 0) fprintf(out, ", \"hipblaslt_auto_nn_stream_us\": %.3f, \"hipblaslt_auto_tn_stream_us\": %.3f", st_at_nn, st_at_tn);
+    if (interleaved)
+      fprintf(out, ", \"protocol\": {\"interleaved\": 1, \"reverse\": %d, \"rounds\": %d, \"stream_rounds\": %d, \"autotune_from_cache\": [%d, %d]}",
+              g_reverse ? 1 : 0, il_rounds, il_stream_rounds, at_cached[0], at_cached[1]);
     if (nt_us > 0) fprintf(out, ", \"stream_plain_us\": %.3f, \"stream_nt_us\": %.3f", nt_plain_us, nt_us);
     if (nt_iso_us > 0) fprintf(out, ", \"nt_adopted_on\": \"stream\", \"isolated_plain_us\": %.3f, \"isolated_nt_us\": %.3f", nt_plain_iso_us, nt_iso_us);
     if (st_ours > 0)
@@ -834,7 +942,10 @@ static int cmd_bench(const Shape& sh, const char* cfg_name, int splits, int grou
     return rc;
   }
   if (g_power) {
-    const int rc = power_bench(sh, cfg >= 0 ? hgemm_mi355x_config_name(cfg) : "generic", launch, sets, g_seconds);
+    // (label = the whole plan: the same geometry with and without non-temporal stores are different variants of the energy table)
+    const std::string label = std::string(cfg >= 0 ? hgemm_mi355x_config_name(cfg) : "generic") + ":" + std::to_string(splits) + ":" + std::to_string(group) +
+                              (use_lib_plan ? " (shipped plan)" : "");
+    const int rc = power_bench(sh, label.c_str(), launch, sets, g_seconds);
     for (auto& s : sets) free_set(s);
     return rc;
   }
@@ -871,6 +982,8 @@ int main(int argc, char** argv) {
     else if (a == "--nt") g_try_nt = true;
     else if (a == "--rank") g_rank_both = std::string(next()) == "both";
     else if (a == "--stream") g_stream_report = true;
+    else if (a == "--interleave") g_interleave = true;
+    else if (a == "--reverse") g_reverse = true;
     else if (a == "--cand-file") { if (!load_cand_file(next())) { fprintf(stderr, "cannot read --cand-file\n"); return 2; } }
     else if (a == "--configs") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) g_config_filter.push_back(t); }
     else if (a == "--plan-only") g_plan_only = true;
@@ -915,7 +1028,8 @@ int main(int argc, char** argv) {
       // stage counts, one to seven K = 32 slices of tail, the last one partial.  The tail at the item seams of a persistent walk
       // needs more items than resident workgroups: `check --shapes 4352_4352_328 --configs <family q>`, tools/lab/gpu_round4_j.sh)
       shapes = parse_shapes("64_64_64,64_4096_64,128_192_256,200_136_128,256_256_1024,320_448_512,512_1024_2048,1000_520_192,"
-                            "1000_520_200,65_30_100,33_17_40,300_260_2048,300_260_2104,520_392_728");
+                            "1000_520_200,65_30_100,33_17_40,300_260_2048,300_260_2104,520_392_728,"
+                            "96_80_4096");   // (round 6: K / 64 = 64, so that the 37- and 48-way single-launch splits run)
     return cmd_check(shapes);
   }
   if (mode == "tune") {

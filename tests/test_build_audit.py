@@ -465,18 +465,37 @@ def test_the_audits_hold_at_a_second_optimisation_level(tmp_path_factory):
             assert not m0_provenance_violations(lines), name
 
 
-def test_kernels_of_the_measured_library_keep_their_instruction_streams(isa_text):
-    """The round's grid records (plan reports against hipBLASLt-autotune, parity / tolerance records, PMC table, bench) stay valid only
-    while the kernels they ran are untouched, and "I did not edit that function" is not evidence: variants are instantiations of the
-    same templates and share non-inlined helpers.  So every kernel of the library the closing run measured
-    (profiles/r05_isa_fingerprint_closing_run_library.json, made by tools/isa_fingerprint.py from the sources of that commit) still
-    exists with the same instruction stream modulo basic-block numbering -- all of them, no exceptions -- and nothing was added.
+def _r6_change_allowed(name: str) -> bool:
+    """Kernels round 6 touched on purpose (see the test below)."""
+    epi = re.search(r"EEELi(\d+)EEEvNS", name)
+    epi = int(epi.group(1)) if epi else -1
+    if "15hgemm_tn_kernel" in name or "18hgemm_tn_wd_kernel" in name:
+        return epi == 2                                   # EPI_FUSED
+    if "18hgemm_tn_rs_kernel" in name:
+        return epi in (2, 10)                             # EPI_FUSED, EPI_FUSED | ktail
+    if "18hgemm_tn_sq_kernel" in name:
+        two_resident = re.search(r"CfgSQILi(128ELi128ELi2ELi2ELi1E|192ELi128E|128ELi192E)", name) is not None
+        fused_small = (epi & 3) == 3 and re.search(r"CfgSQILi(256ELi128E|128ELi128ELi2ELi2ELi2E)", name) is not None
+        return two_resident or fused_small                # the CU-phase prologue; the row-ahead combine (<= 128 accumulators)
+    return False
 
-    Against round 4's library (profiles/r04_isa_fingerprint_call_k_library.json, 296 kernels) round 5 changed, knowingly: every
-    family-q kernel (the "m0" clobbers add an s_nop in front of some M0 writes, the walk's phase flags add a prologue block), the
-    three staged-epilogue kernels of family s (plain lgkmcnt(0) in the LDS round trip), family w's long-K kernels (16- / 8-slice
-    trips); it added family q's kstagger variants and the two-resident members.  The classic family, family r and both stream-K
-    kernels are instruction-for-instruction round 4's: 212 kernels, checked below."""
+
+def test_kernels_of_the_measured_library_keep_their_instruction_streams(isa_text):
+    """A round's grid records (plan reports, parity / tolerance records, PMC table, bench) stay valid only while the kernels they
+    ran are untouched, and "I did not edit that function" is not evidence: variants are instantiations of the same templates and
+    share non-inlined helpers.  So the kernels are fingerprinted (tools/isa_fingerprint.py: instruction stream modulo basic-block
+    numbering) against the library a closing run measured.
+
+    Round 6 against round 5's closing library (profiles/r05_isa_fingerprint_closing_run_library.json, 348 kernels): the SAME 348
+    kernels, none added, and exactly 103 changed, knowingly --
+      * the single-launch split-K ("fused") variants whose last arriver now adds the slabs in batches (fused_combine): 28 of the
+        classic family, 24 of family r (plain + ktail), 9 of family w, and the fused variants of the family-q members with at most
+        128 accumulator registers;
+      * every variant of the three two-resident members of family q (the HGEMM_PLAN_CU_PHASE prologue).
+    Every other kernel -- all plain / two-pass / stream-K kernels of families t, r, w, s, and every variant of q256x256 (the
+    headline kernel), q192x256, q256x192, q128x256, plain q256x128 / q128x128_k128 -- is instruction-for-instruction round 5's:
+    245 kernels, checked below.  The closing run of round 6 fingerprints its own library
+    (profiles/r06_isa_fingerprint_closing_run_library.json, when present: everything must match it)."""
     import json
     import sys
 
@@ -486,16 +505,22 @@ def test_kernels_of_the_measured_library_keep_their_instruction_streams(isa_text
     now = isa_fingerprint.fingerprints(isa_text)
     base = json.loads((REPO / "profiles" / "r05_isa_fingerprint_closing_run_library.json").read_text())["kernels"]
     assert len(base) == 348 and set(base) == set(now), (sorted(set(base) ^ set(now))[:4])
-    assert not [k for k in base if now[k] != base[k]], [k for k in base if now[k] != base[k]][:4]
+    changed = [k for k in base if now[k] != base[k]]
+    assert not [k for k in changed if not _r6_change_allowed(k)], [k for k in changed if not _r6_change_allowed(k)][:4]
+    assert len(changed) == 103, len(changed)
+    # the headline kernel and its variants are round 5's
+    assert not [k for k in changed if "CfgSQILi256ELi256E" in k]
+    r6 = REPO / "profiles" / "r06_isa_fingerprint_closing_run_library.json"
+    if r6.exists():
+        closing = json.loads(r6.read_text())["kernels"]
+        assert set(closing) == set(now) and not [k for k in closing if now[k] != closing[k]], [k for k in closing if now.get(k) != closing[k]][:4]
+    # round 4 -> round 5 (kept: what round 5 changed knowingly): of round 4's 296 kernels the classic family, family r and both
+    # stream-K kernels came through round 5 untouched
     r4 = json.loads((REPO / "profiles" / "r04_isa_fingerprint_call_k_library.json").read_text())["kernels"]
-    assert len(r4) == 296 and not set(r4) - set(now)
-    same = [k for k in r4 if now[k] == r4[k]]
-    changed = [k for k in r4 if now[k] != r4[k]]
-    assert len(same) == 212 and all(re.search(r"hgemm_tn_(sq|sp|wd)_kernel", k) for k in changed), [k for k in changed if not re.search(r"hgemm_tn_(sq|sp|wd)_kernel", k)][:3]
-    for fam in ("15hgemm_tn_kernel", "18hgemm_tn_rs_kernel", "18hgemm_tn_sk_kernel", "21hgemm_tn_rs_sk_kernel"):
-        assert not [k for k in changed if fam in k], fam
-    # family s: only the staged (wide) epilogues changed
-    assert all(re.search(r"CfgSPI\w+EEELi1EEEvNS", k) for k in changed if "sp_kernel" in k)
-    added = sorted(set(now) - set(r4))
+    assert len(r4) == 296 and not set(r4) - set(base)
+    same = [k for k in r4 if base[k] == r4[k]]
+    ch5 = [k for k in r4 if base[k] != r4[k]]
+    assert len(same) == 212 and all(re.search(r"hgemm_tn_(sq|sp|wd)_kernel", k) for k in ch5)
+    added = sorted(set(base) - set(r4))
     # kstagger variants (epilogue id + 16) of the 16x16x32 members of family q, and every variant of the two-resident members
     assert added and all(re.search(r"hgemm_tn_sq_kernel.*(ELi(16|17|18|19)EEEvNS|CfgSQILi(192ELi128|128ELi192)E)", k) for k in added), added[:3]

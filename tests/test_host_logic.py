@@ -718,7 +718,7 @@ def test_plan_flags_of_round_5_are_flags_not_split_counts(lib):
     lib.hgemm_mi355x_config_by_name.argtypes = [ctypes.c_char_p]
     q = lib.hgemm_mi355x_config_by_name(b"q256x256_w2x2")
     base = lib.hgemm_mi355x_model_us(q, 1, 8192, 8192, 512)
-    for flag in (0x80000, 0x200000, 0x400000, 0x800000, 0x80000 | 0x200000 | 0x20000):
+    for flag in (0x80000, 0x200000, 0x400000, 0x800000, 0x1000000, 0x80000 | 0x200000 | 0x20000):
         assert lib.hgemm_mi355x_model_us(q, 1 | flag, 8192, 8192, 512) == base
     info = (ctypes.c_int * 8)()
     for name, lds in ((b"q192x128_w2x2", 80 * 1024), (b"q128x192_w2x2", 80 * 1024), (b"q128x128_w2x2", 64 * 1024)):
@@ -735,7 +735,8 @@ def test_plan_flags_of_round_5_are_flags_not_split_counts(lib):
     assert form_text(1 | 0x200000 | 0x20000) == " phase offset"
     d = bench.plan_dict(b"q256x256_w2x2", 2 | 0x10000 | 0x20000 | 0x80000 | 0x200000, 4)
     assert d == {"config": "q256x256_w2x2", "splits": 2, "group_m": 4, "fused_split_k": True, "nt_store": True, "streamk": False,
-                 "xcd_stagger": True, "nt_loads": False, "phase_offset": True, "wave_priority": False, "phase_offset4": False}
+                 "xcd_stagger": True, "nt_loads": False, "phase_offset": True, "wave_priority": False, "phase_offset4": False, "cu_phase": False}
+    assert bench.plan_dict(b"q128x128_w2x2", 1 | 0x1000000, 4)["cu_phase"] and form_text(1 | 0x1000000) == " phase offset inside the CU"
 
 
 def test_first_use_selection_is_off_by_default_and_lists_launchable_candidates(lib):
