@@ -344,7 +344,7 @@ def cpu_baseline(workload, seconds: float = 12.0) -> dict:
 def measured_traffic(mnk: str) -> tuple[float | None, str | None]:
     """(HBM bytes per launch, source file) of the shape's kernel from the committed rocprofv3 PMC summaries (profiles/),
     newest round first; (None, None) when no summary covers the shape."""
-    for name in (f"r05_pmc_{mnk}.json", f"r04_pmc_{mnk}.json", f"r03_pmc_{mnk}.json", "pmc_summary.json", f"r02_pmc_{mnk}.json", f"r01_pmc_{mnk}.json"):
+    for name in (f"r06_pmc_{mnk}.json", f"r05_pmc_{mnk}.json", f"r04_pmc_{mnk}.json", f"r03_pmc_{mnk}.json", "pmc_summary.json", f"r02_pmc_{mnk}.json", f"r01_pmc_{mnk}.json"):
         f = REPO / "profiles" / name
         if f.exists():
             try:

@@ -246,8 +246,8 @@ double median_of(std::vector<float>& v) {
 // ---- on-disk cache of autotune winners ----------------------------------------------------------------------------------------
 // Text, one record per line:  tn M N K compute16 algo_index best_ms candidates warm timed budget_s solution_name
 // The solution index is hipBLASLt's own (hipblaslt_ext::getIndexFromAlgo / getAlgosFromIndex): valid for the library build that
-// wrote it -- a record whose index the running library does not accept for the problem (matmulIsAlgoSupported) is ignored and the
-// search runs again.  A record is reused only if it was searched with at least the budget the caller asks for now.
+// wrote it -- a record whose index does not resolve to the recorded solution name in the running library, or that the library does
+// not accept for the problem (matmulIsAlgoSupported), is ignored and the search runs again.  A record is reused only if it was searched with at least the budget the caller asks for now.
 struct AutotuneRecord {
   int tn, M, N, K, compute16, algo_index, candidates, warm, timed;
   double best_ms, budget_s;
@@ -277,12 +277,13 @@ void cache_load_locked() {
   if (g_cache_path.empty()) return;
   FILE* f = fopen(g_cache_path.c_str(), "r");
   if (!f) return;
-  char line[1024];
+  static char line[8192];   // (hipBLASLt solution names run to ~700 characters)
   while (fgets(line, sizeof line, f)) {
     if (line[0] == '#' || line[0] == '\n') continue;
     AutotuneRecord r;
-    char name[768] = "";
-    if (sscanf(line, "%d %d %d %d %d %d %lf %d %d %d %lf %767s", &r.tn, &r.M, &r.N, &r.K, &r.compute16, &r.algo_index, &r.best_ms,
+    static char name[4096];
+    name[0] = 0;
+    if (sscanf(line, "%d %d %d %d %d %d %lf %d %d %d %lf %4095s", &r.tn, &r.M, &r.N, &r.K, &r.compute16, &r.algo_index, &r.best_ms,
                &r.candidates, &r.warm, &r.timed, &r.budget_s, name) < 11) continue;
     r.solution = name;
     g_cache.push_back(r);   // (a later line of the same problem supersedes an earlier one: lookups scan from the back)
@@ -290,16 +291,16 @@ void cache_load_locked() {
   fclose(f);
 }
 
-bool cache_lookup(bool tn, int M, int N, int K, bool compute16, double budget_s, AutotuneRecord* out) {
+// every record of the problem that was searched with at least the budget asked for now, newest first (a file may hold records
+// of several hipBLASLt builds -- the torch wheel bundles its own, `hgemm_tune` links /opt/rocm's: cache_apply tells them apart)
+std::vector<AutotuneRecord> cache_lookup(bool tn, int M, int N, int K, bool compute16, double budget_s) {
+  std::vector<AutotuneRecord> out;
   std::lock_guard<std::mutex> lk(g_cache_mutex);
   cache_load_locked();
   for (auto it = g_cache.rbegin(); it != g_cache.rend(); ++it)
-    if (it->tn == (int)tn && it->M == M && it->N == N && it->K == K && it->compute16 == (int)compute16) {
-      if (it->budget_s + 1e-9 < budget_s) return false;   // searched with a smaller box than asked for now: search again
-      *out = *it;
-      return true;
-    }
-  return false;
+    if (it->tn == (int)tn && it->M == M && it->N == N && it->K == K && it->compute16 == (int)compute16 && it->budget_s + 1e-9 >= budget_s)
+      out.push_back(*it);
+  return out;
 }
 
 void cache_store(const AutotuneRecord& r) {
@@ -322,6 +323,15 @@ bool cache_apply(LtProblem& p, const AutotuneRecord& r) {
   std::vector<int> idx{r.algo_index};
   std::vector<hipblasLtMatmulHeuristicResult_t> res;
   if (hipblaslt_ext::getAlgosFromIndex(g_auto.handle, idx, res) != HIPBLAS_STATUS_SUCCESS || res.empty()) return false;
+  // A solution index belongs to ONE build of the hipBLASLt kernel library: the same number names another kernel in another build
+  // (measured in round 6: a cache searched by a process that linked /opt/rocm's hipBLASLt was useless to the torch processes of the
+  // sweep, whose wheel bundles its own).  The record is only taken when the index resolves to the solution NAME that was searched.
+  if (!r.solution.empty() && r.solution != "-") {
+    std::string now = hipblaslt_ext::getSolutionNameFromAlgo(g_auto.handle, res[0].algo);
+    for (char& ch : now) if (ch == ' ' || ch == '\n' || ch == '\t') ch = '_';
+    if (now.size() > 700) now.resize(700);
+    if (now != r.solution) return false;
+  }
   const float alpha32 = 1.0f, beta32 = 0.0f;
   const f16 alpha16 = (f16)1.0f, beta16 = (f16)0.0f;
   const bool h = p.compute16;
@@ -345,15 +355,13 @@ int autotune_find(bool tn, int M, int N, int K, int acc) {
   int st = lt_prepare(g_auto, p, tn, M, N, K, acc, 100, cands);
   if (st != HGEMM_OK) return st;
   g_last_from_cache[tn ? 1 : 0] = 0;
-  {
-    AutotuneRecord rec;
-    if (cache_lookup(tn, M, N, K, p.compute16, autotune_budget_s(), &rec) && cache_apply(p, rec)) {
+  for (const AutotuneRecord& rec : cache_lookup(tn, M, N, K, p.compute16, autotune_budget_s()))
+    if (cache_apply(p, rec)) {
       g_last_from_cache[tn ? 1 : 0] = 1;
       ++g_cache_hits;
       return HGEMM_OK;
     }
-    ++g_cache_misses;
-  }
+  ++g_cache_misses;
   int n_algo = (int)cands.size();
   {
     // Time box, part 1 (before anything is allocated): when one round over all candidates would already take more

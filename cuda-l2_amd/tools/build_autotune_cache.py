@@ -33,7 +33,13 @@ def main(argv=None) -> int:
     ap.add_argument("--acc", choices=["fp32", "fp16"], default="fp32")
     ap.add_argument("--time_limit", type=float, default=0.0, help="stop after this many seconds (resumable)")
     ap.add_argument("--report", type=Path, default=None, help="write a JSON summary here")
+    ap.add_argument("--with-torch", action="store_true", help="import torch first, so that the hipBLASLt the torch wheel bundles is the one "
+                    "mapped -- the build the harness processes (benchmarking_*.py, tools/sweep.py) search and run.  Without it this "
+                    "process links /opt/rocm's hipBLASLt, the build bin/hgemm_tune uses.  A solution index is only valid for the build "
+                    "that searched it (the library checks the recorded solution name), so the two flavours live side by side in one file")
     args = ap.parse_args(argv)
+    if args.with_torch:
+        import torch  # noqa: F401  (side effect: its bundled ROCm libraries are loaded before libhgemm_mi355x.so asks for them)
     lib = ctypes.CDLL(str(PKG_DIR / "lib" / "libhgemm_mi355x.so"))
     lib.hgemm_hipblaslt_autotune_best_ms.restype = ctypes.c_double
     lib.hgemm_hipblaslt_autotune_set_cache.argtypes = [ctypes.c_char_p]
@@ -70,7 +76,7 @@ def main(argv=None) -> int:
     h, ms = ctypes.c_int(), ctypes.c_int()
     records = lib.hgemm_hipblaslt_autotune_cache_stats(ctypes.byref(h), ctypes.byref(ms))
     lib.hgemm_hipblaslt_autotune_destroy()
-    out = {"cache": str(args.cache), "records": records, "searched": searched, "cache_hits": hit, "failed": failed,
+    out = {"cache": str(args.cache), "hipblaslt": "torch wheel" if args.with_torch else "/opt/rocm", "records": records, "searched": searched, "cache_hits": hit, "failed": failed,
            "search_seconds": round(search_s, 1), "wall_seconds": round(time.time() - t0, 1), "acc": args.acc,
            "compute16_fallback_seen": sorted(fallback)}
     print(json.dumps(out))

@@ -75,11 +75,25 @@ def main(argv=None) -> int:
             sp = splits & MASK
             is_split = sp > 1 and not (splits & STREAMK)
             small_out = m * n <= 1024 * 1024 and k >= 1024
-            if not (is_split or small_out):
-                continue
-            flags = splits & ~(MASK | FUSED | NT)
             bm, bn = tile_of(cfg)
             kg = kgran_of(cfg)
+            tiles0 = -(-m // bm) * -(-n // bn)
+            # a plan that leaves CUs idle because splitting used to cost a second dispatch or a serial combine: fewer than 1.5
+            # work items per CU and a K long enough to cut (2048 x 1024 x 4096 ships 128 tiles of 128 x 128, unsplit)
+            under_filled = not (splits & STREAMK) and tiles0 * sp < 384 and k >= 1024 and cfg[0] in "tqr"
+            if not (is_split or small_out or under_filled):
+                continue
+            flags = splits & ~(MASK | FUSED | NT)
+            if under_filled and not is_split:
+                for s2 in (2, 4, 8):
+                    if (k // kg) // s2 < 4 or tiles0 * s2 > 1024:
+                        continue
+                    add(f"{cfg}:{s2 | FUSED | flags}:{group}")
+                    add(f"{cfg}:{s2 | flags}:{group}")
+                    if cfg.startswith("q128x128_w2x2") and not cfg.endswith("_k128") and k % 128 == 0:
+                        add(f"q128x128_w2x2_k128:{s2 | FUSED}:{group}")
+                    if cfg.startswith("q"):
+                        add(f"t128x128_w2x2_m16_s3:{s2 | FUSED}:{group}")
             if is_split:
                 for s2 in (sp, sp * 2, max(2, sp // 2), sp * 4):
                     if s2 < 2 or s2 > 64 or (k // kg) // s2 < 2:

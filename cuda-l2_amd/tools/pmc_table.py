@@ -4,7 +4,7 @@ representative grid shape of every kernel geometry that serves at least `--min-r
   python tools/pmc_table.py shapes [--min-rows 5]          -> the shape list (one M_N_K per line, largest-flop row of
                                                              each geometry plus the BASELINE shapes)
   python tools/pmc_table.py table PASS_ROOT SHAPES.txt       -> JSON table from the passes tools/pmc_table.sh collected
-  python tools/pmc_table.py baseline TABLE.json OUT_DIR      -> OUT_DIR/r05_pmc_<M_N_K>.json of the BASELINE.json shapes
+  python tools/pmc_table.py baseline TABLE.json OUT_DIR      -> OUT_DIR/r06_pmc_<M_N_K>.json of the BASELINE.json shapes
                                                              (what bench.py's roofline.traffic reads)
 
 Collection (tools/pmc_table.sh): three rocprofv3 --pmc passes (SQ + GRBM counters, FETCH_SIZE, WRITE_SIZE -- their TCC
@@ -28,6 +28,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent.parent
 BASELINE_SHAPES = ["64_4096_64", "512_4096_4096", "4096_4096_4096"]
 MFMA_PEAK_TF, HBM_PEAK_TBS = 2500.0, 8.0
+ROUND = "r06"   # prefix of the files `baseline` writes (profiles/<ROUND>_pmc_<M_N_K>.json)
 
 
 def table_rows():
@@ -85,19 +86,19 @@ def main() -> int:
         print("\n".join(pick_shapes(a.min_rows)))
         return 0
     if a.cmd == "baseline":
-        # baseline <table.json> <out dir>: one r05_pmc_<M_N_K>.json per BASELINE.json shape, the form bench.py's
+        # baseline <table.json> <out dir>: one r06_pmc_<M_N_K>.json per BASELINE.json shape, the form bench.py's
         # measured_traffic() reads (dominant_kernel.{mnk, hbm_bytes_per_launch})
         tab = json.load(open(a.root))
         for row in tab["rows"]:
             if row["mnk"] not in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
                 continue
-            rec = {"source": tab["source"], "hbm_bytes": tab["hbm_bytes"], "table": "profiles/r05_pmc_table.json",
+            rec = {"source": tab["source"], "hbm_bytes": tab["hbm_bytes"], "table": f"profiles/{ROUND}_pmc_table.json",
                    "dominant_kernel": {"mnk": row["mnk"], "kernel": row["kernels"][0] if row["kernels"] else None,
                                        "hbm_bytes_per_launch": row["hbm_bytes_per_launch"],
                                        "algorithmic_bytes_per_launch": row["algorithmic_bytes_per_launch"],
                                        "avg_kernel_us_profiled": row["avg_kernel_us_profiled"]},
                    "row": row}
-            with open(f"{a.shapes}/r05_pmc_{row['mnk']}.json", "w") as f:
+            with open(f"{a.shapes}/{ROUND}_pmc_{row['mnk']}.json", "w") as f:
                 json.dump(rec, f, indent=1)
         return 0
     shapes = [s.strip() for s in open(a.shapes) if s.strip()]

@@ -273,7 +273,9 @@ int hgemm_hipblaslt_autotune_tn(const void* a, const void* b_col_major, void* c,
  * 1000-shape grid x two accumulate trees x two modes that is the same search eight thousand times.  With a cache file -- the
  * environment's HGEMM_AUTOTUNE_CACHE, or hgemm_hipblaslt_autotune_set_cache(path) (NULL / "" = none) -- find_best_* first looks the
  * problem (layout, M, N, K, compute type) up: a record searched with at least the current HGEMM_AUTOTUNE_MAX_SECONDS whose
- * hipBLASLt solution index the running library accepts for the problem is taken as the winner without timing anything;
+ * hipBLASLt solution index resolves to the recorded solution name in the running library (an index is only valid for the build of
+ * hipBLASLt that searched it: the torch wheel bundles its own, bin/hgemm_tune links /opt/rocm's -- records of both may share a
+ * file) and which the library accepts for the problem is taken as the winner without timing anything;
  * otherwise the search runs and appends its winner (text, one line per problem: tn M N K compute16 algo_index best_ms candidates
  * warm timed budget_s solution_name).  hgemm_hipblaslt_autotune_from_cache(tn): 1 when the last find_best of that layout was a
  * cache hit; _cache_stats: records held, hits / misses of this process. */
