@@ -62,7 +62,7 @@ EVENT_STRIDE = 16              # every 16th launch of the timed region carries d
 
 
 PLAN_FLAGS = (("fused_split_k", 0x10000), ("nt_store", 0x20000), ("streamk", 0x40000), ("xcd_stagger", 0x80000), ("nt_loads", 0x100000),
-              ("phase_offset", 0x200000), ("wave_priority", 0x400000), ("phase_offset4", 0x800000), ("cu_phase", 0x1000000))
+              ("phase_offset", 0x200000), ("wave_priority", 0x400000), ("phase_offset4", 0x800000))
 
 
 def plan_dict(name, splits: int, group_m: int) -> dict:

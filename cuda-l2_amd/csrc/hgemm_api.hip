@@ -841,8 +841,7 @@ int hgemm_mi355x_launch(int config_id, int splits_arg, int group_m, const void* 
   g.k_chunk = K; g.splits = 1; g.tiles_m = g.tiles_n = 1; g.group_m = 1; g.items = 1;
   g.tail_first = 0; g.tail_tiles = 0;
   g.flags = ((splits_arg & HGEMM_PLAN_NT_STORE) ? 1 : 0) | ((splits_arg & HGEMM_PLAN_RS_XCD_STAGGER) ? 2 : 0) | ((splits_arg & HGEMM_PLAN_RS_NT_LOADS) ? 4 : 0) |
-            ((splits_arg & HGEMM_PLAN_PHASE_OFFSET) ? 8 : 0) | ((splits_arg & HGEMM_PLAN_WAVE_PRIORITY) ? 16 : 0) | ((splits_arg & HGEMM_PLAN_PHASE_OFFSET4) ? 32 : 0) |
-            ((splits_arg & HGEMM_PLAN_CU_PHASE) ? 64 : 0);
+            ((splits_arg & HGEMM_PLAN_PHASE_OFFSET) ? 8 : 0) | ((splits_arg & HGEMM_PLAN_WAVE_PRIORITY) ? 16 : 0) | ((splits_arg & HGEMM_PLAN_PHASE_OFFSET4) ? 32 : 0);
   g.sk = StreamK{1, 0, 0, 1, FastDiv{0u, 0u, 0u}};
 #ifdef HGEMM_ABLATION
   g.debug = g_debug_flags;

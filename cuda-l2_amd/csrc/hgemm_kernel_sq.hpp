@@ -541,26 +541,6 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_sq_kernel(const GemmArg
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       if (hw & 1u) __builtin_amdgcn_s_setprio(2);
     }
-    // flags bit 6 (HGEMM_PLAN_CU_PHASE, round 6), two-resident members: the phase offset INSIDE a CU.  The two workgroups of a CU
-    // start together and do the same work, so they reach their epilogues together: two waves per SIMD, yet the matrix pipe idles
-    // while both store and the store path idles while both multiply ("two workgroups per CU do NOT overlap
-    // one's epilogue with the other's K loop").  The phase groups of bit 3 / 5 are taken from the workgroup's index inside its XCD,
-    // which gives the two residents of a CU the SAME group.  Here the workgroup whose waves sit in the odd hardware wave slots
-    // enters its walk half an item period late -- the period of a workgroup that shares its CU: both K loops back to back plus an
-    // epilogue -- so that one resident's epilogue runs under the other's K loop: the ping-pong of the reference's warp-specialised
-    // H100 kernels (KernelTmaWarpSpecializedPingpong, kernels/h100_F32F16F16F32/1024_16384_128.cu:157) with two 4-wave workgroups
-    // as the two halves.  Walks of several items only (a single item would just finish half a period later).
-    if ((g.flags & 64) && walk.count > 1) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      if (hw & 1u) {
-        const int nk0 = g.k_chunk / (BK * CFG::KT);
-        const int kloop = nk0 * 2 * CFG::T * 16;                       // MFMA cycles of one item's K loop (shader cycles, roughly)
-        const int half = kloop + CFG::BM * CFG::BN / 24;               // half of (two K loops + one epilogue)
-#pragma clang loop unroll(disable)
-        for (int c = 0; c < half; c += 1024) __builtin_amdgcn_s_sleep(16);
-      }
-    }
   }
 
   // fragment lane mapping (hgemm_kernel_sp.hpp): MI = 16: row lane & 15, 16-B chunk 4h + (lane >> 4);

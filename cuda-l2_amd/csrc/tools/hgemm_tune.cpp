@@ -412,9 +412,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
                                    4 | HGEMM_SPLITK_FUSED | HGEMM_PLAN_XCD_STAGGER,
                                    // the walk's phase flags (prologue only: a sleep / a priority): alone, together, with a stagger
                                    1 | HGEMM_PLAN_PHASE_OFFSET, 1 | HGEMM_PLAN_PHASE_OFFSET4, 1 | HGEMM_PLAN_PHASE_OFFSET8, 1 | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_NT_STORE,
-                                   2 | HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_XCD_STAGGER,
-                                   // round 6: the phase offset inside a CU (two-resident members; a prologue sleep like the others)
-                                   1 | HGEMM_PLAN_CU_PHASE, 1 | HGEMM_PLAN_CU_PHASE | HGEMM_PLAN_NT_STORE, 2 | HGEMM_PLAN_CU_PHASE | HGEMM_PLAN_XCD_STAGGER});
+                                   2 | HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_WAVE_PRIORITY | HGEMM_PLAN_XCD_STAGGER});
       for (int splits : forms) {
         const bool sk = (splits & HGEMM_PLAN_STREAMK) != 0;
         const int sp = sk ? 2 : (splits & HGEMM_SPLITK_MASK);   // (sp > 1: run twice, one raster group)
@@ -462,7 +460,7 @@ static int cmd_check(const std::vector<Shape>& shapes) {
     if (g_config_filter.empty() || std::find(g_config_filter.begin(), g_config_filter.end(), std::string(cname)) != g_config_filter.end())
       printf(" %s", cname);
   }
-  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused 3|fused 5|fused 7|fused 13|fused 16|fused 21|fused 32|fused 37|fused 48|fused (3|fused .. 48|fused: K >= 2048) streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger 1|phase-offset 1|phase-offset4 1|phase-offset8 1|wave-priority|nt-store 2|phase-offset|wave-priority|xcd-stagger 1|cu-phase 1|cu-phase|nt-store 2|cu-phase|xcd-stagger, raster groups 1 4\n");
+  printf("\ncheck-forms: 1 2 3 8 2|fused 8|fused 3|fused 5|fused 7|fused 13|fused 16|fused 21|fused 32|fused 37|fused 48|fused (3|fused .. 48|fused: K >= 2048) streamk|0 streamk|5 streamk|37 streamk|300 (stream-K on the geometries that have the kernel), family r also 1|xcd-stagger|nt-loads 2|fused|xcd-stagger 3|nt-loads streamk|37|xcd-stagger|nt-loads, family q also 1|xcd-stagger 1|xcd-stagger|nt-store 3|xcd-stagger 4|fused|xcd-stagger 1|phase-offset 1|phase-offset4 1|phase-offset8 1|wave-priority|nt-store 2|phase-offset|wave-priority|xcd-stagger, raster groups 1 4\n");
   printf("check: %d runs, %d failures (bit-exact against the exact integer result of 0/1 inputs)\n", runs, failures);
   return failures ? 1 : 0;
 }

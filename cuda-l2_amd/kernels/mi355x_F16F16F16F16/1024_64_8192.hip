@@ -1,6 +1,6 @@
 // M=1024 N=64 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t32x64_w1x2_m16_s4, split-K 8, raster group 32  [tuned on MI355X: 13.5 us, 79 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t32x64_w1x2_m16_s4, split-K 8 (single launch), raster group 32  [tuned on MI355X (round 6): 12.7 us, 84.5 TFLOP/s fused split-K (back to back 10.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 64, 8192, "t32x64_w1x2_m16_s4", 8, 32)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 64, 8192, "t32x64_w1x2_m16_s4", 65544, 32)

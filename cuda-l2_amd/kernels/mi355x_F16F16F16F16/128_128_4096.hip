@@ -1,6 +1,6 @@
 // M=128 N=128 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry w16x16_k4, split-K 4, raster group 1  [tuned on MI355X (round 5): 9.2 us, 14.5 TFLOP/s two-pass split-K (back to back 6.6 us), verified against the CPU oracle]
+// plan: geometry w16x32_k4, split-K 8 (single launch), raster group 1  [tuned on MI355X (round 6): 8.9 us, 15.0 TFLOP/s fused split-K (back to back 6.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 128, 4096, "w16x16_k4", 4, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 128, 4096, "w16x32_k4", 65544, 1)

@@ -1,6 +1,6 @@
 // M=128 N=4096 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w4x2_m16_s4, split-K 4 (single launch), raster group 1  [tuned on MI355X: 25.4 us, 339 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t128x64_w2x2_m16_s4, split-K 4 (single launch), raster group 1  [tuned on MI355X (round 6): 26.5 us, 323.9 TFLOP/s fused split-K (back to back 23.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 4096, 8192, "t128x64_w4x2_m16_s4", 65540, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 4096, 8192, "t128x64_w2x2_m16_s4", 65540, 1)

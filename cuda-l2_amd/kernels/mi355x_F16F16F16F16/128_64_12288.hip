@@ -1,6 +1,6 @@
 // M=128 N=64 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry w16x32_k4, split-K 16, raster group 1  [tuned on MI355X (round 5): 11.3 us, 17.8 TFLOP/s two-pass split-K (back to back 8.9 us), verified against the CPU oracle]
+// plan: geometry w16x16_k4, split-K 8 (single launch), raster group 1  [tuned on MI355X (round 6): 10.6 us, 19.0 TFLOP/s fused split-K (back to back 8.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 64, 12288, "w16x32_k4", 16, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 64, 12288, "w16x16_k4", 65544, 1)

@@ -1,6 +1,6 @@
 // M=2048 N=256 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 2 (single launch), raster group 8  [tuned on MI355X: 16.0 us, 269 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 4 (single launch), raster group 8  [tuned on MI355X (round 6): 15.9 us, 269.4 TFLOP/s fused split-K (back to back 13.1 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 256, 4096, "t64x64_w2x2_m16_s4", 65538, 8)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 256, 4096, "t64x64_w2x2_m16_s4", 65540, 8)

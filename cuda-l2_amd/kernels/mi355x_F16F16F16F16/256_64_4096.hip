@@ -1,6 +1,6 @@
 // M=256 N=64 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry w16x16_k4, split-K 4 (single launch), raster group 4  [tuned on MI355X (round 4): 9.3 us, 14.4 TFLOP/s fused split-K (back to back 6.9 us), verified against the CPU oracle]
+// plan: geometry w16x32_k4, split-K 8 (single launch), raster group 1  [tuned on MI355X (round 6): 8.9 us, 15.1 TFLOP/s fused split-K (back to back 6.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 64, 4096, "w16x16_k4", 65540, 4)
+HGEMM_MI355X_SHAPE_ENTRY(256, 64, 4096, "w16x32_k4", 65544, 1)

@@ -1,6 +1,6 @@
 // M=512 N=4096 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 2 (single launch), raster group 4  [tuned on MI355X (round 5): 70.0 us, 736.5 TFLOP/s fused split-K (back to back 66.8 us), verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 6): 61.2 us, 842.7 TFLOP/s two-pass split-K (back to back 61.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 12288, "q128x128_w2x2", 65538, 4)
+HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 12288, "q256x128_w2x2", 4, 4)

@@ -1,6 +1,6 @@
 // M=64 N=2048 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 16, raster group 1  [tuned on MI355X (round 5): 21.2 us, 202.2 TFLOP/s two-pass split-K (back to back 18.5 us), verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 8 (single launch), raster group 1  [tuned on MI355X (round 6): 24.2 us, 177.5 TFLOP/s fused split-K (back to back 21.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 2048, 16384, "q128x128_w2x2", 16, 1)
+HGEMM_MI355X_SHAPE_ENTRY(64, 2048, 16384, "t64x64_w2x2_m16_s4", 65544, 1)

@@ -1,6 +1,6 @@
 // M=64 N=256 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t32x64_w1x2_m16_s4, split-K 32, raster group 4  [tuned on MI355X: 11.7 us, 34 TFLOP/s, verified against the CPU oracle]
+// plan: geometry w16x32_k4, split-K 8 (single launch), raster group 1  [tuned on MI355X (round 6): 11.9 us, 33.8 TFLOP/s fused split-K (back to back 9.1 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 256, 12288, "t32x64_w1x2_m16_s4", 32, 4)
+HGEMM_MI355X_SHAPE_ENTRY(64, 256, 12288, "w16x32_k4", 65544, 1)

@@ -1,6 +1,6 @@
 // M=1024 N=2048 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 4, raster group 2  [tuned on MI355X: 79.5 us, 865 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 6): 72.8 us, 944.5 TFLOP/s two-pass split-K (back to back 72.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 2048, 16384, "q256x128_w2x2", 4, 2)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 2048, 16384, "q256x128_w2x2", 4, 4)

@@ -1,6 +1,6 @@
 // M=1024 N=256 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x4_m16_s4, split-K 8 (single launch), raster group 4  [tuned on MI355X: 19.5 us, 330 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 8, raster group 4  [tuned on MI355X (round 6): 20.9 us, 308.0 TFLOP/s two-pass split-K (back to back 18.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 256, 12288, "t64x128_w2x4_m16_s4", 65544, 4)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 256, 12288, "t64x128_w2x4_m16_s4", 8, 4)

@@ -1,6 +1,6 @@
 // M=128 N=16384 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 5): 86.7 us, 594.2 TFLOP/s fused split-K, K stagger per XCD (back to back 88.6 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 83.7 us, 615.6 TFLOP/s fused split-K, K stagger per XCD (back to back 84.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 16384, 12288, "q128x128_w2x2", 589826, 4)
+HGEMM_MI355X_SHAPE_ENTRY(128, 16384, 12288, "q128x128_w2x2_k128", 589826, 4)

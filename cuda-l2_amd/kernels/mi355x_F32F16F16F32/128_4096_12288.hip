@@ -1,6 +1,6 @@
 // M=128 N=4096 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 6, raster group 4  [tuned on MI355X (round 5): 27.6 us, 466.5 TFLOP/s two-pass split-K (back to back 25.1 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 8, raster group 4  [tuned on MI355X (round 6): 34.4 us, 374.3 TFLOP/s two-pass split-K (back to back 32.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 4096, 12288, "q128x128_w2x2", 6, 4)
+HGEMM_MI355X_SHAPE_ENTRY(128, 4096, 12288, "q128x128_w2x2_k128", 8, 4)

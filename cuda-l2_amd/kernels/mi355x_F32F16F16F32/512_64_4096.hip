@@ -1,6 +1,6 @@
 // M=512 N=64 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry w16x16_k4, split-K 2 (single launch), raster group 4  [tuned on MI355X (round 4): 10.5 us, 25.6 TFLOP/s fused split-K (back to back 8.1 us), verified against the CPU oracle]
+// plan: geometry w32x32_k4, split-K 8 (single launch), raster group 1  [tuned on MI355X (round 6): 9.9 us, 27.1 TFLOP/s fused split-K (back to back 7.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 64, 4096, "w16x16_k4", 65538, 4)
+HGEMM_MI355X_SHAPE_ENTRY(512, 64, 4096, "w32x32_k4", 65544, 1)

@@ -1,6 +1,6 @@
 // M=512 N=8192 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 1, raster group 4  [tuned on MI355X: 116.6 us, 884 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 6): 98.8 us, 1043.3 TFLOP/s two-pass split-K (back to back 100.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 8192, 12288, "q128x128_w2x2_k128", 1, 4)
+HGEMM_MI355X_SHAPE_ENTRY(512, 8192, 12288, "q256x256_w2x2", 4, 4)

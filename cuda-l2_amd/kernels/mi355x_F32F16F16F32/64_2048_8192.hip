@@ -1,6 +1,6 @@
 // M=64 N=2048 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 8, raster group 8  [tuned on MI355X: 14.7 us, 146 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 8 (single launch), raster group 8  [tuned on MI355X (round 6): 15.3 us, 140.0 TFLOP/s fused split-K (back to back 12.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 2048, 8192, "t64x64_w2x2_m16_s4", 8, 8)
+HGEMM_MI355X_SHAPE_ENTRY(64, 2048, 8192, "t64x64_w2x2_m16_s4", 65544, 8)

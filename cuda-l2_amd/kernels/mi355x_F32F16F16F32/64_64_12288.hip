@@ -1,6 +1,6 @@
 // M=64 N=64 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry w16x16_k4, split-K 16, raster group 1  [tuned on MI355X (round 5): 10.5 us, 9.5 TFLOP/s two-pass split-K (back to back 8.0 us), verified against the CPU oracle]
+// plan: geometry w16x32_k4, split-K 16 (single launch), raster group 1  [tuned on MI355X (round 6): 9.5 us, 10.6 TFLOP/s fused split-K (back to back 7.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 64, 12288, "w16x16_k4", 16, 1)
+HGEMM_MI355X_SHAPE_ENTRY(64, 64, 12288, "w16x32_k4", 65552, 1)

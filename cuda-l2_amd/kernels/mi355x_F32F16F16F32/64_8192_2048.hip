@@ -1,6 +1,6 @@
 // M=64 N=8192 K=2048  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t32x64_w1x2_m16_s4, split-K 2 (single launch), raster group 2  [tuned on MI355X: 12.8 us, 168 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 2 (single launch), raster group 4  [tuned on MI355X (round 6): 13.2 us, 163.2 TFLOP/s fused split-K (back to back 10.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 2048, "t32x64_w1x2_m16_s4", 65538, 2)
+HGEMM_MI355X_SHAPE_ENTRY(64, 8192, 2048, "t64x64_w2x2_m16_s4", 65538, 4)

@@ -1,6 +1,6 @@
 // M=8192 N=256 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 4, K stagger per XCD, raster group 2  [tuned on MI355X (round 5): 93.8 us, 732.3 TFLOP/s two-pass split-K, K stagger per XCD (back to back 88.8 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 84.8 us, 810.4 TFLOP/s fused split-K, K stagger per XCD (back to back 87.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 16384, "q256x128_w2x2", 524292, 2)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 16384, "q128x128_w2x2_k128", 589826, 4)

@@ -1,6 +1,6 @@
 // M=8192 N=256 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 2, K stagger per XCD, raster group 16  [tuned on MI355X (round 5): 49.5 us, 693.6 TFLOP/s two-pass split-K, K stagger per XCD (back to back 51.3 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 47.7 us, 719.7 TFLOP/s fused split-K, K stagger per XCD (back to back 48.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 8192, "q128x128_w2x2_k128", 524290, 16)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 8192, "q128x128_w2x2_k128", 589826, 4)

@@ -62,7 +62,7 @@ def write_shape_file(mnk: str, acc: str, device_type: str = "mi355x", plan=None,
     path = out_dir / f"{mnk}.hip"
     entry = "hgemm_mi355x_fp32" if acc == "fp32" else "hgemm_mi355x_fp16"
     flags = "".join(f", {t}" for bit, t in ((0x80000, "K stagger per XCD"), (0x100000, "NT loads of the streamed operand"), (0x200000, "phase offset"),
-                                            (0x800000, "phase offset x4"), (0x400000, "wave priority"), (0x1000000, "phase offset inside the CU")) if splits & bit)
+                                            (0x800000, "phase offset x4"), (0x400000, "wave priority")) if splits & bit)
     flags = flags.replace(", phase offset, phase offset x4", ", phase offset x8")   # (both bits: eight phase groups)
     text = (
         f"// M={m} N={n} K={k}  {ACC_TEXT[acc]}  MI355X / gfx950\n"

@@ -26,7 +26,7 @@ ROW = re.compile(r'\s*\{(\d+), (\d+), (\d+), "([^"]+)", (\d+), (\d+)\},(.*)')
 
 
 FLAG_TEXT = ((0x80000, "K stagger per XCD"), (0x100000, "NT loads of the streamed operand"), (0x200000, "phase offset"),
-             (0x800000, "phase offset x4"), (0x400000, "wave priority"), (0x1000000, "phase offset inside the CU"))
+             (0x800000, "phase offset x4"), (0x400000, "wave priority"))
 
 
 def form_text(splits: int) -> str:

@@ -108,11 +108,6 @@ typedef enum { HGEMM_ACC_FP32 = 0, HGEMM_ACC_FP16 = 1 } hgemm_acc_t;
  *   waves of a SIMD get different static priorities, so one workgroup's epilogue runs under the other's K loop. */
 #define HGEMM_PLAN_PHASE_OFFSET  0x200000
 #define HGEMM_PLAN_WAVE_PRIORITY 0x400000
-/* HGEMM_PLAN_CU_PHASE (round 6), two-resident members, walks of several items: the workgroup in the odd hardware wave slots of its
- *   CU enters its walk half an item period late, so that one resident's epilogue runs under the other's K loop (the ping-pong of the
- *   reference's warp-specialised H100 kernels, kernels/h100_F32F16F16F32/1024_16384_128.cu:157, with two 4-wave workgroups as the
- *   halves).  Bit-identical results. */
-#define HGEMM_PLAN_CU_PHASE 0x1000000
 #define HGEMM_PLAN_PHASE_OFFSET4 0x800000   /* four phase groups a quarter period apart instead of two half a period apart */
 #define HGEMM_PLAN_PHASE_OFFSET8 (HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_PHASE_OFFSET4)   /* both bits: eight groups an eighth of a period apart */
 

@@ -37,6 +37,18 @@ def _shipped():
     return out
 
 
+def _shipped_r05():
+    """The table as round 5 shipped it: today's table with round 6's recorded row changes undone (tuning/r06_*_changes.jsonl, newest
+    first) -- round 5's reports and records describe THAT table."""
+    out = _shipped()
+    for f in sorted((PKG / "tuning").glob("r06_*_changes.jsonl"), reverse=True):
+        for c in reversed(_recs(f)):
+            assert out[c["mnk"]] == (c["to"]["config"], c["to"]["splits"], c["to"]["group_m"]) or any(
+                c2["mnk"] == c["mnk"] for f2 in (PKG / "tuning").glob("r06_*_changes.jsonl") if f2 > f for c2 in _recs(f2)), c["mnk"]
+            out[c["mnk"]] = (c["from"]["config"], c["from"]["splits"], c["from"]["group_m"])
+    return out
+
+
 def test_bench_record_and_its_rocprof_stats_match_the_design_text():
     b = json.loads((REPO / "profiles" / "r04_bench.json").read_text())
     assert b["metric"] == "HGEMM TFLOP/s" and b["n_gpus"] == 1 and b["dtype"] == "f16" and b["vs_baseline"] is None
@@ -214,8 +226,12 @@ def test_tuner_results_were_checked_before_they_were_timed():
     script of the call the check comes before the tune."""
     man = json.loads((PKG / "tuning" / "r04_checked_before_timed.json").read_text())
     man.update(json.loads((PKG / "tuning" / "r05_checked_before_timed.json").read_text()))     # round 5: same rule, same test
-    tune_files = sorted(p for rnd in ("r04", "r05") for p in (PKG / "tuning").glob(f"{rnd}_*_mi355x.jsonl") if "plan_report" not in p.name)
-    assert len([p for p in tune_files if p.name.startswith("r05_")]) >= 8
+    man.update(json.loads((PKG / "tuning" / "r06_checked_before_timed.json").read_text()))     # round 6
+    tune_files = sorted(p for rnd in ("r04", "r05", "r06") for p in (PKG / "tuning").glob(f"{rnd}_*_mi355x.jsonl") if "plan_report" not in p.name)
+    assert len([p for p in tune_files if p.name.startswith("r05_")]) >= 8 and len([p for p in tune_files if p.name.startswith("r06_")]) >= 3
+    # round 6's single-launch forms at every batch depth of the last arriver's combine are in the check's own form list
+    forms6 = re.search(r"^check-forms:(.*)$", (REPO / "profiles" / "r06_check_call_f_all_geometries_and_forms.log").read_text(), re.M).group(1)
+    assert all(f"{n}|fused" in forms6 for n in (2, 3, 5, 7, 8, 13, 16, 21, 32, 37, 48))
     # round 5's family-q plan forms (kstagger variants, phase flags) are in the closing check's own form list
     forms = re.search(r"^check-forms:(.*)$", (REPO / "profiles" / "r05_check_final.log").read_text(), re.M).group(1)
     assert all(f in forms for f in ("1|xcd-stagger", "4|fused|xcd-stagger", "1|phase-offset", "1|phase-offset4", "1|phase-offset8", "1|wave-priority|nt-store"))
@@ -238,7 +254,7 @@ def test_tuner_results_were_checked_before_they_were_timed():
         ti = script.index(man[key]["tune_marker"]) if "tune_marker" in man[key] else script.index(" tune ")
         assert " check" in script and ci < ti, man[key]["script"]
     # plan-only reports time shipped plans (the table's own parity records cover those): nothing else may be in them
-    for rep in list((PKG / "tuning").glob("r04_*plan_report*_mi355x.jsonl")) + list((PKG / "tuning").glob("r05_*plan_report*_mi355x.jsonl")):
+    for rep in [p for rnd in ("r04", "r05", "r06") for p in (PKG / "tuning").glob(f"{rnd}_*plan_report*_mi355x.jsonl")]:
         assert all(len(r["candidates"]) == 1 for r in _recs(rep)), rep.name
 
 
@@ -279,7 +295,7 @@ def test_round5_north_star_report_matches_design_and_readme():
 
     path = PKG / "tuning" / "r05_grid_plan_report_autotune_mi355x.jsonl"
     rep = _recs(path)
-    shipped = _shipped()
+    shipped = _shipped_r05()
     assert len(rep) >= 600 and len({r["mnk"] for r in rep}) == len(rep)
     for r in rep:
         assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]      # the shipped plans, nothing else
@@ -343,7 +359,7 @@ def test_round5_off_grid_traffic_and_parity_records():
     runs = re.search(r"check: (\d+) runs, 0 failures", log)
     assert runs and f"{int(runs.group(1)):,}".replace(",", " ") in d
     named = set(re.search(r"^check-configs:(.*)$", log, re.M).group(1).split())
-    assert {c for c, _, _ in _shipped().values()} <= named               # every shipped geometry is in the closing check
+    assert {c for c, _, _ in _shipped_r05().values()} <= named           # every geometry round 5 shipped is in its closing check
     # the phase-offset rows re-checked on a fresh box (section 4.14, call N): shipped plan against the same plan without the flag
     gains = []
     for r in _recs(PKG / "tuning" / "r05_phase_rows_recheck_mi355x.jsonl"):
@@ -351,7 +367,7 @@ def test_round5_off_grid_traffic_and_parity_records():
         ph = [c for c in r["candidates"] if c["splits"] & 0xA00000 and c.get("stream_us")]
         pl = [c for c in r["candidates"] if not c["splits"] & 0xA00000 and c.get("stream_us")]
         if ph and pl:
-            assert (ph[0]["config"], ph[0]["splits"], ph[0]["group_m"]) == _shipped()[r["mnk"]]
+            assert (ph[0]["config"], ph[0]["splits"], ph[0]["group_m"]) == _shipped_r05()[r["mnk"]]
             gains.append(fig(pl[0]) / fig(ph[0]))
     assert len(gains) == 52 and f"+{(_gm(gains) - 1) * 100:.1f} % for the flag" in d
     assert f"{sum(g > 1.015 for g in gains)} gain more than 1.5 %, {sum(g < 0.985 for g in gains)} lose more than 1.5 %" in d
@@ -369,7 +385,7 @@ def test_round5_off_grid_traffic_and_parity_records():
     import collections
 
     tab = json.loads((REPO / "profiles" / "r05_pmc_table.json").read_text())
-    counts = collections.Counter(c for c, _, _ in _shipped().values())
+    counts = collections.Counter(c for c, _, _ in _shipped_r05().values())
     assert {c for c, n in counts.items() if n >= 5} <= {r["plan"]["config"] for r in tab["rows"] if r["plan"]}
     rows = {r["mnk"]: r for r in tab["rows"]}
     for mnk in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
