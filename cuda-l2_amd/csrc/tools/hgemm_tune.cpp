@@ -288,6 +288,7 @@ static bool load_cand_file(const char* path) {
   }
   return true;
 }
+static bool g_with_shipped = false;            // --with-shipped: the library's plan for the shape joins the candidates
 static bool g_fused_too = false;               // --fused: also time the single-launch form of every split-K plan
 static bool g_streamk_too = false;             // --streamk: also time the stream-K plans (HGEMM_PLAN_STREAMK | workgroups)
 
@@ -524,6 +525,14 @@ static int cmd_tune(const std::vector<Shape>& shapes, const char* out_path, doub
       if (cands.empty()) cands = candidates(sh, keep_ratio, std::min(max_cand, 6));   // a shape the file does not know
     } else {
       cands = candidates(sh, keep_ratio, max_cand);
+    }
+    if (g_with_shipped && !g_plan_only) {   // --with-shipped: the library's own plan (tuned table / planner) is measured beside the candidates
+      Plan p{0, 1, 1, 0.0};
+      hgemm_mi355x_plan(sh.M, sh.N, sh.K, &p.cfg, &p.splits, &p.group_m);
+      p.model_us = p.cfg >= 0 ? hgemm_mi355x_model_us(p.cfg, p.splits, sh.M, sh.N, sh.K) : 0.0;
+      bool have = false;
+      for (const Plan& c : cands) have = have || (c.cfg == p.cfg && c.splits == p.splits && c.group_m == p.group_m);
+      if (!have) cands.insert(cands.begin(), p);
     }
     struct Res { Plan p; double us; double iso_us = -1, stream = -1; };
     std::vector<Res> res;
@@ -976,6 +985,7 @@ int main(int argc, char** argv) {
     else if (a == "--out") out_path = next();
     else if (a == "--autotune") autotune = true;
     else if (a == "--fused") g_fused_too = true;
+    else if (a == "--with-shipped") g_with_shipped = true;
     else if (a == "--streamk") g_streamk_too = true;
     else if (a == "--nt") g_try_nt = true;
     else if (a == "--rank") g_rank_both = std::string(next()) == "both";

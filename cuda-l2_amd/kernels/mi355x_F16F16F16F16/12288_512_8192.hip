@@ -1,6 +1,6 @@
 // M=12288 N=512 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q192x256_w2x2, split-K 2, K stagger per XCD, raster group 8  [tuned on MI355X (round 5): 93.8 us, 1098.4 TFLOP/s two-pass split-K, K stagger per XCD (back to back 97.1 us), verified against the CPU oracle]
+// plan: geometry q192x256_w2x2, split-K 2, raster group 4  [tuned on MI355X (round 6): 98.7 us, 1044.4 TFLOP/s two-pass split-K (back to back 96.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 512, 8192, "q192x256_w2x2", 524290, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 512, 8192, "q192x256_w2x2", 2, 4)

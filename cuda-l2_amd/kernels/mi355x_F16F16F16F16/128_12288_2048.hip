@@ -1,6 +1,6 @@
 // M=128 N=12288 K=2048  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 23.4 us, 275.3 TFLOP/s fused split-K, K stagger per XCD (back to back 19.9 us), verified against the CPU oracle]
+// plan: geometry t128x64_w2x2_m16_s4, split-K 1, raster group 1  [tuned on MI355X (round 6): 21.5 us, 299.4 TFLOP/s (back to back 18.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 12288, 2048, "q128x128_w2x2_k128", 589826, 4)
+HGEMM_MI355X_SHAPE_ENTRY(128, 12288, 2048, "t128x64_w2x2_m16_s4", 1, 1)

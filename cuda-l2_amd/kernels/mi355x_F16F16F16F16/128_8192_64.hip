@@ -1,6 +1,6 @@
 // M=128 N=8192 K=64  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w2x2_m16_s4, split-K 1, raster group 8  [tuned on MI355X: 6.3 us, 21 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 1, raster group 2  [tuned on MI355X (round 6): 6.6 us, 20.5 TFLOP/s (back to back 3.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 64, "t128x64_w2x2_m16_s4", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 64, "t64x128_w2x4_m16_s4", 1, 2)

@@ -1,6 +1,6 @@
 // M=2048 N=2048 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 4, K stagger per XCD, raster group 8  [tuned on MI355X (round 5): 115.2 us, 1193.0 TFLOP/s two-pass split-K, K stagger per XCD (back to back 116.3 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 6): 121.4 us, 1132.3 TFLOP/s two-pass split-K (back to back 119.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 2048, 16384, "q256x256_w2x2", 524292, 8)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 2048, 16384, "q256x256_w2x2", 4, 4)

@@ -1,6 +1,6 @@
 // M=256 N=1024 K=16384  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 16, raster group 4  [tuned on MI355X (round 6): 24.4 us, 352.0 TFLOP/s two-pass split-K (back to back 22.1 us), verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 8, raster group 4  [tuned on MI355X (round 6): 24.8 us, 346.4 TFLOP/s two-pass split-K (back to back 22.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 1024, 16384, "q128x128_w2x2_k128", 16, 4)
+HGEMM_MI355X_SHAPE_ENTRY(256, 1024, 16384, "t64x128_w2x4_m16_s4", 8, 4)

@@ -1,6 +1,6 @@
 // M=256 N=2048 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 8, raster group 4  [tuned on MI355X (round 6): 22.5 us, 381.1 TFLOP/s two-pass split-K (back to back 20.8 us), verified against the CPU oracle]
+// plan: geometry t128x64_w4x2_m16_s4, split-K 4 (single launch), raster group 2  [tuned on MI355X (round 6): 23.7 us, 362.4 TFLOP/s fused split-K (back to back 21.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 2048, 8192, "q128x128_w2x2_k128", 8, 4)
+HGEMM_MI355X_SHAPE_ENTRY(256, 2048, 8192, "t128x64_w4x2_m16_s4", 65540, 2)

@@ -1,6 +1,6 @@
 // M=1024 N=16384 K=256  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x256_w2x4_m16_s2, stream-K on 256 workgroups, raster group 8  [tuned on MI355X (round 4): 21.5 us, 400.3 TFLOP/s stream-K, 256 workgroups (back to back 18.2 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, raster group 4  [tuned on MI355X (round 6): 19.2 us, 448.3 TFLOP/s (back to back 16.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 16384, 256, "t128x256_w2x4_m16_s2", 262400, 8)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 16384, 256, "q256x256_w2x2", 1, 4)

@@ -1,6 +1,6 @@
 // M=1024 N=8192 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 8  [tuned on MI355X (round 5): 148.3 us, 1390.5 TFLOP/s K stagger per XCD (back to back 150.0 us), verified against the CPU oracle]
+// plan: geometry s256x256_w2x2, split-K 2, raster group 4  [tuned on MI355X (round 6): 177.4 us, 1162.4 TFLOP/s two-pass split-K (back to back 170.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 12288, "q256x128_w2x2", 655361, 8)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 12288, "s256x256_w2x2", 2, 4)

@@ -1,6 +1,6 @@
 // M=128 N=2048 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 12, raster group 1  [tuned on MI355X (round 5): 20.5 us, 314.0 TFLOP/s two-pass split-K (back to back 17.9 us), verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 4 (single launch), raster group 2  [tuned on MI355X (round 6): 24.6 us, 261.9 TFLOP/s fused split-K (back to back 21.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 2048, 12288, "q128x128_w2x2", 12, 1)
+HGEMM_MI355X_SHAPE_ENTRY(128, 2048, 12288, "t64x64_w2x2_m16_s4", 65540, 2)

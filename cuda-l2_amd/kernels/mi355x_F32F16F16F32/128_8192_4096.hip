@@ -1,6 +1,6 @@
 // M=128 N=8192 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 4, raster group 4  [tuned on MI355X (round 5): 22.8 us, 377.1 TFLOP/s two-pass split-K (back to back 20.4 us), verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 1, raster group 2  [tuned on MI355X (round 6): 27.2 us, 316.0 TFLOP/s (back to back 23.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 4096, "q128x128_w2x2", 4, 4)
+HGEMM_MI355X_SHAPE_ENTRY(128, 8192, 4096, "t64x64_w2x2_m16_s4", 1, 2)

@@ -1,6 +1,6 @@
 // M=2048 N=128 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w4x2_m16_s4, split-K 8, raster group 2  [tuned on MI355X (round 6): 23.4 us, 275.5 TFLOP/s two-pass split-K (back to back 21.3 us), verified against the CPU oracle]
+// plan: geometry t64x64_w2x2_m16_s4, split-K 4 (single launch), raster group 4  [tuned on MI355X (round 6): 24.7 us, 260.8 TFLOP/s fused split-K (back to back 21.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 128, 12288, "t128x64_w4x2_m16_s4", 8, 2)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 128, 12288, "t64x64_w2x2_m16_s4", 65540, 4)

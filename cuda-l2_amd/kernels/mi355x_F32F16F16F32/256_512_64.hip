@@ -1,6 +1,6 @@
 // M=256 N=512 K=64  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x64_w2x2_m16_s2, split-K 1, raster group 16  [tuned on MI355X: 6.2 us, 3 TFLOP/s, verified against the CPU oracle]
+// plan: geometry w32x32_k4, split-K 1, raster group 4  [tuned on MI355X (round 6): 6.4 us, 2.6 TFLOP/s (back to back 2.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(256, 512, 64, "t128x64_w2x2_m16_s2", 1, 16)
+HGEMM_MI355X_SHAPE_ENTRY(256, 512, 64, "w32x32_k4", 1, 4)

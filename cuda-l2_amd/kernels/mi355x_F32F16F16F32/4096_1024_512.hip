@@ -1,6 +1,6 @@
 // M=4096 N=1024 K=512  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t128x128_w2x4_m16_s4, split-K 1, raster group 2  [tuned on MI355X: 9.7 us, 444 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 6): 11.3 us, 380.8 TFLOP/s (back to back 8.1 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 1024, 512, "t128x128_w2x4_m16_s4", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 1024, 512, "q128x128_w2x2", 1, 8)

@@ -1,6 +1,6 @@
 // M=4096 N=16384 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, phase offset, raster group 4  [tuned on MI355X (round 5): 403.2 us, 1363.4 TFLOP/s phase offset (back to back 399.0 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 6): 396.9 us, 1385.2 TFLOP/s (back to back 395.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 16384, 4096, "q256x256_w2x2", 2097153, 4)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 16384, 4096, "q256x256_w2x2", 1, 8)

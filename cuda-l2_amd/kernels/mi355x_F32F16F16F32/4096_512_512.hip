@@ -1,6 +1,6 @@
 // M=4096 N=512 K=512  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x64_w2x2_m16_s4, split-K 1, raster group 2  [tuned on MI355X: 8.8 us, 243 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 1, raster group 8  [tuned on MI355X (round 6): 8.8 us, 245.1 TFLOP/s (back to back 6.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 512, 512, "t64x64_w2x2_m16_s4", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 512, 512, "t64x128_w2x4_m16_s4", 1, 8)

@@ -1,6 +1,6 @@
 // M=512 N=12288 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x192_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 5): 82.0 us, 1257.4 TFLOP/s (back to back 82.2 us), verified against the CPU oracle]
+// plan: geometry q256x192_w2x2, split-K 2, raster group 2  [tuned on MI355X (round 6): 98.4 us, 1048.0 TFLOP/s two-pass split-K (back to back 96.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 12288, 8192, "q128x192_w2x2", 131073, 4)
+HGEMM_MI355X_SHAPE_ENTRY(512, 12288, 8192, "q256x192_w2x2", 2, 2)

@@ -1,6 +1,6 @@
 // M=512 N=64 K=256  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry w32x16_k4, split-K 1, raster group 2  [tuned on MI355X (round 4): 6.2 us, 2.7 TFLOP/s (back to back 2.7 us), verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s3, split-K 1, raster group 2  [tuned on MI355X (round 6): 6.2 us, 2.7 TFLOP/s (back to back 4.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 64, 256, "w32x16_k4", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(512, 64, 256, "t64x128_w2x4_m16_s3", 1, 2)

@@ -1,6 +1,6 @@
 // M=64 N=512 K=128  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t32x32_w1x1_m16_s4, split-K 1, raster group 2  [tuned on MI355X: 6.2 us, 1 TFLOP/s, verified against the CPU oracle]
+// plan: geometry w32x32_k4, split-K 1, raster group 2  [tuned on MI355X (round 6): 6.4 us, 1.3 TFLOP/s (back to back 3.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(64, 512, 128, "t32x32_w1x1_m16_s4", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(64, 512, 128, "w32x32_k4", 1, 2)

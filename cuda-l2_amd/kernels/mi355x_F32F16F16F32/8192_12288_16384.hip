@@ -1,6 +1,6 @@
 // M=8192 N=12288 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, K stagger per XCD, phase offset, raster group 8  [tuned on MI355X (round 5): 2433.5 us, 1355.5 TFLOP/s K stagger per XCD, phase offset (back to back 2368.9 us), verified against the CPU oracle]
+// plan: geometry s256x256_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 6): 2397.3 us, 1376.0 TFLOP/s (back to back 2298.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 12288, 16384, "q256x256_w2x2", 2621441, 8)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 12288, 16384, "s256x256_w2x2", 1, 8)

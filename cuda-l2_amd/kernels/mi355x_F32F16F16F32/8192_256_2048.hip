@@ -1,6 +1,6 @@
 // M=8192 N=256 K=2048  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry t64x128_w2x2_m16_s4, split-K 1, raster group 2  [tuned on MI355X: 17.8 us, 483 TFLOP/s, verified against the CPU oracle]
+// plan: geometry t64x128_w2x4_m16_s4, split-K 1, raster group 8  [tuned on MI355X (round 6): 19.8 us, 434.7 TFLOP/s (back to back 16.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 2048, "t64x128_w2x2_m16_s4", 1, 2)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 2048, "t64x128_w2x4_m16_s4", 1, 8)
