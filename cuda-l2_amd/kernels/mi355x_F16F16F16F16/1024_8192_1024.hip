@@ -1,6 +1,6 @@
 // M=1024 N=8192 K=1024  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 32  [tuned on MI355X (round 5): 20.2 us, 849.6 TFLOP/s K stagger per XCD (back to back 17.5 us), verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 1, non-temporal C stores, raster group 32  [tuned on MI355X (round 6): 21.1 us, 814.2 TFLOP/s (back to back 17.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 1024, "q256x128_w2x2", 655361, 32)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 1024, "q256x128_w2x2", 131073, 32)

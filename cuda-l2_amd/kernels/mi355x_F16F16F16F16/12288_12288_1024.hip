@@ -1,6 +1,6 @@
 // M=12288 N=12288 K=1024  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X (round 5): 247.5 us, 1249.6 TFLOP/s (back to back 243.9 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 6): 244.0 us, 1267.3 TFLOP/s (back to back 245.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 12288, 1024, "q256x256_w2x2", 131073, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 12288, 1024, "q256x256_w2x2", 131073, 4)

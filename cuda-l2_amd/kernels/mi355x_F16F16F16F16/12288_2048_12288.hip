@@ -1,6 +1,6 @@
 // M=12288 N=2048 K=12288  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q192x256_w2x2, split-K 1, K stagger per XCD, raster group 4  [tuned on MI355X (round 5): 437.8 us, 1412.8 TFLOP/s K stagger per XCD (back to back 439.8 us), verified against the CPU oracle]
+// plan: geometry q192x256_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 6): 432.8 us, 1429.1 TFLOP/s (back to back 435.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 2048, 12288, "q192x256_w2x2", 524289, 4)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 2048, 12288, "q192x256_w2x2", 131073, 4)

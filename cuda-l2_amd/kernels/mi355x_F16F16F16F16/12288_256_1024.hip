@@ -1,6 +1,6 @@
 // M=12288 N=256 K=1024  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 5): 14.7 us, 439.5 TFLOP/s (back to back 13.2 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 1, raster group 4  [tuned on MI355X (round 6): 14.9 us, 431.2 TFLOP/s (back to back 13.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 256, 1024, "q128x128_w2x2", 131073, 4)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 256, 1024, "q128x128_w2x2", 1, 4)

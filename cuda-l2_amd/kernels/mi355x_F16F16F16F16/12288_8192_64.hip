@@ -1,6 +1,6 @@
 // M=12288 N=8192 K=64  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 5): 44.2 us, 291.8 TFLOP/s (back to back 42.0 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X (round 6): 46.2 us, 278.8 TFLOP/s (back to back 41.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 8192, 64, "q128x128_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 8192, 64, "q128x128_w2x2", 131073, 8)

@@ -1,6 +1,6 @@
 // M=16384 N=1024 K=256  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X: 15.2 us, 565 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 6): 17.0 us, 504.1 TFLOP/s (back to back 14.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 1024, 256, "q256x256_w2x2", 131073, 8)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 1024, 256, "q256x256_w2x2", 131073, 4)

@@ -1,6 +1,6 @@
 // M=16384 N=16384 K=256  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset x4, raster group 8  [tuned on MI355X (round 5): 177.9 us, 772.7 TFLOP/s phase offset x4 (back to back 178.1 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset x8, raster group 8  [tuned on MI355X (round 6): 172.6 us, 796.1 TFLOP/s phase offset x8 (back to back 171.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 16384, 256, "q256x256_w2x2", 8519681, 8)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 16384, 256, "q256x256_w2x2", 10616833, 8)

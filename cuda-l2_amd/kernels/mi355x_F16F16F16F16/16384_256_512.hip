@@ -1,6 +1,6 @@
 // M=16384 N=256 K=512  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 1, raster group 8  [tuned on MI355X: 9.6 us, 447 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 8  [tuned on MI355X (round 6): 11.8 us, 362.8 TFLOP/s K stagger per XCD (back to back 8.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 256, 512, "q128x128_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 256, 512, "q128x128_w2x2", 655361, 8)

@@ -1,6 +1,6 @@
 // M=4096 N=16384 K=128  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q192x128_w2x2, split-K 1, non-temporal C stores, phase offset x4, raster group 4  [tuned on MI355X (round 5): 38.5 us, 446.5 TFLOP/s phase offset x4 (back to back 38.8 us), verified against the CPU oracle]
+// plan: geometry q192x128_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 6): 36.7 us, 468.1 TFLOP/s (back to back 35.9 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 16384, 128, "q192x128_w2x2", 8519681, 4)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 16384, 128, "q192x128_w2x2", 131073, 4)

@@ -1,6 +1,6 @@
 // M=4096 N=4096 K=8192  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 6): 199.1 us, 1380.9 TFLOP/s (back to back 195.8 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, raster group 4  [tuned on MI355X (round 6): 182.8 us, 1503.4 TFLOP/s (back to back 189.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 4096, 8192, "q256x256_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 4096, 8192, "q256x256_w2x2", 1, 4)

@@ -1,6 +1,6 @@
 // M=512 N=4096 K=4096  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 29.4 us, 584.7 TFLOP/s fused split-K, K stagger per XCD (back to back 27.3 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 2 (single launch), K stagger per XCD, raster group 8  [tuned on MI355X (round 6): 30.4 us, 564.4 TFLOP/s fused split-K, K stagger per XCD (back to back 27.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 4096, "q128x128_w2x2_k128", 589826, 4)
+HGEMM_MI355X_SHAPE_ENTRY(512, 4096, 4096, "q128x128_w2x2_k128", 589826, 8)

@@ -1,6 +1,6 @@
 // M=512 N=8192 K=2048  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X: 22.7 us, 758 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 1, non-temporal C stores, K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 24.3 us, 707.6 TFLOP/s K stagger per XCD (back to back 21.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 8192, 2048, "q128x128_w2x2_k128", 131073, 4)
+HGEMM_MI355X_SHAPE_ENTRY(512, 8192, 2048, "q128x128_w2x2_k128", 655361, 4)

@@ -1,6 +1,6 @@
 // M=8192 N=12288 K=256  F16F16F16F16 (fp16 in, fp32 MFMA accumulate [no fp16-accumulate MFMA on CDNA4], fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, phase offset, raster group 8  [tuned on MI355X (round 5): 76.5 us, 673.9 TFLOP/s phase offset (back to back 74.7 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 8  [tuned on MI355X (round 6): 69.0 us, 746.9 TFLOP/s phase offset (back to back 68.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp16
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 12288, 256, "q256x256_w2x2", 2097153, 8)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 12288, 256, "q256x256_w2x2", 2228225, 8)

@@ -1,6 +1,6 @@
 // M=1024 N=8192 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 2, raster group 2  [tuned on MI355X (round 5): 207.7 us, 1323.7 TFLOP/s two-pass split-K (back to back 216.6 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 2, raster group 8  [tuned on MI355X (round 6): 213.6 us, 1287.0 TFLOP/s two-pass split-K (back to back 218.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 16384, "q256x256_w2x2", 2, 2)
+HGEMM_MI355X_SHAPE_ENTRY(1024, 8192, 16384, "q256x256_w2x2", 2, 8)

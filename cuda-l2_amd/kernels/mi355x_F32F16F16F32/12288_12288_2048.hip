@@ -1,6 +1,6 @@
 // M=12288 N=12288 K=2048  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, raster group 8  [tuned on MI355X: 453.5 us, 1364 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X (round 6): 439.9 us, 1406.0 TFLOP/s (back to back 441.1 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 12288, 2048, "q256x256_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 12288, 2048, "q256x256_w2x2", 131073, 8)

@@ -1,6 +1,6 @@
 // M=12288 N=2048 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q192x256_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 6): 304.5 us, 1354.1 TFLOP/s (back to back 299.9 us), verified against the CPU oracle]
+// plan: geometry q192x256_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 8  [tuned on MI355X (round 6): 290.8 us, 1418.1 TFLOP/s K stagger per XCD (back to back 293.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(12288, 2048, 8192, "q192x256_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(12288, 2048, 8192, "q192x256_w2x2", 655361, 8)

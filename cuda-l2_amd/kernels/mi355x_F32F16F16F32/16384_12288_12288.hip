@@ -1,6 +1,6 @@
 // M=16384 N=12288 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, raster group 4  [tuned on MI355X: 3557.8 us, 1391 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, raster group 4  [tuned on MI355X (round 6): 3337.4 us, 1482.5 TFLOP/s (back to back 3319.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 12288, 12288, "q256x256_w2x2", 1, 4)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 12288, 12288, "q256x256_w2x2", 131073, 4)

@@ -1,6 +1,6 @@
 // M=16384 N=12288 K=128  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset x8, raster group 8  [tuned on MI355X (round 5): 100.3 us, 514.1 TFLOP/s phase offset x8 (back to back 99.1 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset x8, raster group 2  [tuned on MI355X (round 6): 101.2 us, 509.4 TFLOP/s phase offset x8 (back to back 94.8 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 12288, 128, "q256x256_w2x2", 10616833, 8)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 12288, 128, "q256x256_w2x2", 10616833, 2)

@@ -1,6 +1,6 @@
 // M=16384 N=256 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 2 (single launch), K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 156.0 us, 881.2 TFLOP/s fused split-K, K stagger per XCD (back to back 156.6 us), verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 2 (single launch), K stagger per XCD, raster group 2  [tuned on MI355X (round 6): 155.2 us, 885.7 TFLOP/s fused split-K, K stagger per XCD (back to back 152.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 256, 16384, "q256x128_w2x2", 589826, 4)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 256, 16384, "q256x128_w2x2", 589826, 2)

@@ -1,6 +1,6 @@
 // M=16384 N=8192 K=512  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 4  [tuned on MI355X (round 5): 130.6 us, 1052.0 TFLOP/s phase offset (back to back 133.5 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 8  [tuned on MI355X (round 6): 128.7 us, 1068.2 TFLOP/s phase offset (back to back 132.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 8192, 512, "q256x256_w2x2", 2228225, 4)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 8192, 512, "q256x256_w2x2", 2228225, 8)

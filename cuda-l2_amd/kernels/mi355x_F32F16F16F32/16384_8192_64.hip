@@ -1,6 +1,6 @@
 // M=16384 N=8192 K=64  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 4  [tuned on MI355X (round 5): 56.0 us, 307.0 TFLOP/s phase offset (back to back 54.9 us), verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 2  [tuned on MI355X (round 6): 56.9 us, 302.0 TFLOP/s phase offset (back to back 55.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(16384, 8192, 64, "q256x128_w2x2", 2228225, 4)
+HGEMM_MI355X_SHAPE_ENTRY(16384, 8192, 64, "q256x128_w2x2", 2228225, 2)

@@ -1,6 +1,6 @@
 // M=2048 N=16384 K=8192  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, K stagger per XCD, raster group 4  [tuned on MI355X (round 5): 369.7 us, 1486.9 TFLOP/s K stagger per XCD (back to back 374.1 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, K stagger per XCD, raster group 4  [tuned on MI355X (round 6): 364.8 us, 1507.2 TFLOP/s K stagger per XCD (back to back 368.5 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 16384, 8192, "q256x256_w2x2", 524289, 4)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 16384, 8192, "q256x256_w2x2", 655361, 4)

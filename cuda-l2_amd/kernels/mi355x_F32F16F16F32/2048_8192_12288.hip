@@ -1,6 +1,6 @@
 // M=2048 N=8192 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, raster group 8  [tuned on MI355X (round 6): 297.5 us, 1385.9 TFLOP/s (back to back 291.2 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, raster group 4  [tuned on MI355X (round 6): 273.3 us, 1508.4 TFLOP/s (back to back 279.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(2048, 8192, 12288, "q256x256_w2x2", 1, 8)
+HGEMM_MI355X_SHAPE_ENTRY(2048, 8192, 12288, "q256x256_w2x2", 1, 4)

@@ -1,6 +1,6 @@
 // M=4096 N=12288 K=64  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 32  [tuned on MI355X (round 5): 25.8 us, 249.9 TFLOP/s phase offset (back to back 23.0 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 1, non-temporal C stores, phase offset, raster group 4  [tuned on MI355X (round 6): 25.9 us, 249.1 TFLOP/s phase offset (back to back 22.4 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 12288, 64, "q256x256_w2x2", 2228225, 32)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 12288, 64, "q256x256_w2x2", 2228225, 4)

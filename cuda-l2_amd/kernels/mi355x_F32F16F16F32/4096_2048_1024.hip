@@ -1,6 +1,6 @@
 // M=4096 N=2048 K=1024  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x256_w2x2, split-K 1, non-temporal C stores, raster group 2  [tuned on MI355X: 19.7 us, 871 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x256_w2x2, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X (round 6): 20.3 us, 844.6 TFLOP/s (back to back 18.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(4096, 2048, 1024, "q128x256_w2x2", 131073, 2)
+HGEMM_MI355X_SHAPE_ENTRY(4096, 2048, 1024, "q128x256_w2x2", 131073, 8)

@@ -1,6 +1,6 @@
 // M=512 N=12288 K=16384  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x192_w2x2, split-K 2, raster group 2  [tuned on MI355X (round 6): 176.4 us, 1168.8 TFLOP/s two-pass split-K (back to back 177.4 us), verified against the CPU oracle]
+// plan: geometry q256x192_w2x2, split-K 2, K stagger per XCD, raster group 2  [tuned on MI355X (round 6): 176.4 us, 1168.6 TFLOP/s two-pass split-K, K stagger per XCD (back to back 178.2 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 12288, 16384, "q256x192_w2x2", 2, 2)
+HGEMM_MI355X_SHAPE_ENTRY(512, 12288, 16384, "q256x192_w2x2", 524290, 2)

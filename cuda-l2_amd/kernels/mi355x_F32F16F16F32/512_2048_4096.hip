@@ -1,6 +1,6 @@
 // M=512 N=2048 K=4096  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2, split-K 4, K stagger per XCD, raster group 2  [tuned on MI355X (round 5): 20.6 us, 416.2 TFLOP/s two-pass split-K, K stagger per XCD (back to back 18.4 us), verified against the CPU oracle]
+// plan: geometry q128x128_w2x2, split-K 4, raster group 2  [tuned on MI355X (round 6): 24.6 us, 349.8 TFLOP/s two-pass split-K (back to back 19.0 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(512, 2048, 4096, "q128x128_w2x2", 524292, 2)
+HGEMM_MI355X_SHAPE_ENTRY(512, 2048, 4096, "q128x128_w2x2", 4, 2)

@@ -1,6 +1,6 @@
 // M=8192 N=1024 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x256_w2x2, split-K 2, raster group 4  [tuned on MI355X (round 6): 175.5 us, 1174.9 TFLOP/s two-pass split-K (back to back 174.5 us), verified against the CPU oracle]
+// plan: geometry q256x256_w2x2, split-K 2, raster group 2  [tuned on MI355X (round 6): 163.0 us, 1264.9 TFLOP/s two-pass split-K (back to back 166.3 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 1024, 12288, "q256x256_w2x2", 2, 4)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 1024, 12288, "q256x256_w2x2", 2, 2)

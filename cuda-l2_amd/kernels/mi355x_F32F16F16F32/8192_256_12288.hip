@@ -1,6 +1,6 @@
 // M=8192 N=256 K=12288  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q256x128_w2x2, split-K 4, raster group 1  [tuned on MI355X: 69.0 us, 747 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q256x128_w2x2, split-K 4, raster group 8  [tuned on MI355X (round 6): 67.6 us, 762.2 TFLOP/s two-pass split-K (back to back 66.7 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 12288, "q256x128_w2x2", 4, 1)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 256, 12288, "q256x128_w2x2", 4, 8)

@@ -1,6 +1,6 @@
 // M=8192 N=512 K=2048  F32F16F16F32 (fp16 in, fp32 MFMA accumulate, fp16 out)  MI355X / gfx950
-// plan: geometry q128x128_w2x2_k128, split-K 1, non-temporal C stores, raster group 8  [tuned on MI355X: 23.0 us, 747 TFLOP/s, verified against the CPU oracle]
+// plan: geometry q128x128_w2x2_k128, split-K 1, non-temporal C stores, raster group 2  [tuned on MI355X (round 6): 23.6 us, 726.7 TFLOP/s (back to back 21.6 us), verified against the CPU oracle]
 // kernels: csrc/hgemm_kernel*.hpp (instantiated in libhgemm_mi355x.so); geometry table: csrc/hgemm_configs.def
 #define HGEMM_SHAPE_FALLBACK hgemm_mi355x_fp32
 #include "hgemm_shape_entry.hpp"
-HGEMM_MI355X_SHAPE_ENTRY(8192, 512, 2048, "q128x128_w2x2_k128", 131073, 8)
+HGEMM_MI355X_SHAPE_ENTRY(8192, 512, 2048, "q128x128_w2x2_k128", 131073, 2)

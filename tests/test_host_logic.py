@@ -294,7 +294,9 @@ def test_every_shipped_plan_has_an_exact_oracle_record():
                  # round 6: the "fused" re-tune (three passes on three boxes)
                  "r06_candidate_parity_fused_pass1.jsonl", "r06_candidate_parity_fused_pass2.jsonl", "r06_candidate_parity_fused_pass3.jsonl",
                  # ... and the wide re-tune (the model's candidates on the whole grid, three boxes)
-                 "r06_candidate_parity_wide_pass1.jsonl", "r06_candidate_parity_wide_pass2.jsonl", "r06_candidate_parity_wide_pass3.jsonl"):
+                 "r06_candidate_parity_wide_pass1.jsonl", "r06_candidate_parity_wide_pass2.jsonl", "r06_candidate_parity_wide_pass3.jsonl",
+                 # ... and the flag pass (K stagger / NT stores / phase offset / raster group toggles, three boxes)
+                 "r06_candidate_parity_flags_pass1.jsonl", "r06_candidate_parity_flags_pass2.jsonl", "r06_candidate_parity_flags_pass3.jsonl"):
         for ln in (PKG / "tuning" / name).read_text().splitlines():
             r = json.loads(ln)
             if r["pass"] and r["bitwise_equal_unmasked"] and r["guard_bars_intact"] and r["max_diff_masked"] == 0.0:
