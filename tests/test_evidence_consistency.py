@@ -37,14 +37,17 @@ def _shipped():
     return out
 
 
+R06_TABLE_UPDATES = ["r06_retune_fused_changes.jsonl", "r06_retune_wide_changes.jsonl", "r06_retune_flags_changes.jsonl"]   # in the order they were applied
+
+
 def _shipped_r05():
-    """The table as round 5 shipped it: today's table with round 6's recorded row changes undone (tuning/r06_*_changes.jsonl, newest
-    first) -- round 5's reports and records describe THAT table."""
+    """The table as round 5 shipped it: today's table with round 6's recorded row changes undone, newest first -- round 5's reports
+    and records describe THAT table.  (Every undo must find the row in the state the update left it in: the chain is complete.)"""
     out = _shipped()
-    for f in sorted((PKG / "tuning").glob("r06_*_changes.jsonl"), reverse=True):
-        for c in reversed(_recs(f)):
-            assert out[c["mnk"]] == (c["to"]["config"], c["to"]["splits"], c["to"]["group_m"]) or any(
-                c2["mnk"] == c["mnk"] for f2 in (PKG / "tuning").glob("r06_*_changes.jsonl") if f2 > f for c2 in _recs(f2)), c["mnk"]
+    assert sorted(p.name for p in (PKG / "tuning").glob("r06_*_changes.jsonl")) == sorted(R06_TABLE_UPDATES)
+    for name in reversed(R06_TABLE_UPDATES):
+        for c in reversed(_recs(PKG / "tuning" / name)):
+            assert out[c["mnk"]] == (c["to"]["config"], c["to"]["splits"], c["to"]["group_m"]), (name, c["mnk"])
             out[c["mnk"]] = (c["from"]["config"], c["from"]["splits"], c["from"]["group_m"])
     return out
 
