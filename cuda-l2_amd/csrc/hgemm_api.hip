@@ -468,7 +468,9 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
         const KernelEntry& e = g_kernel_table[c];
         if (!k_ok(e, K) || (e.bm > M * 2 && e.bm > 32) || (e.bn > N * 2 && e.bn > 32)) continue;
         for (int s : {1, 2, 4}) {
-          if (s > 1 && K / s < 1024) break;
+          // (round 6: a split of a sibling needs >= 2048 of K per slice -- with 1024 the model took 40 tiles of 256 x 128 at four
+          // single-launch splits for 1968 x 576 x 4096 when its corner moved to the K = 128 stages: 39.1 us against 26.9 for the corner plan)
+          if (s > 1 && K / s < 2048) break;
           if (fill_of(e, s) < fill0) continue;
           const double t = model_us(e, M, N, K, s);
           if (t < best) {
