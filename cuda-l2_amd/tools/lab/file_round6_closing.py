@@ -69,9 +69,6 @@ def part_l():
     cache = L / "r06_hipblaslt_autotune_cache.txt"
     if cache.exists():
         shutil.copy(cache, T / "r06_hipblaslt_autotune_cache.txt")
-    rep = T / "r06_hipblaslt_autotune_cache_build_report_opt_rocm.json"
-    if rep.exists():
-        shutil.copy(rep, dest / "autotune_cache_build_report.json")
     run("tools/sweep_readme_r06.py", "eval_results/r06_sweep", stdout=subprocess.DEVNULL)
     grid = T / "r06_grid_plan_report_autotune_interleaved_mi355x.jsonl"
     if grid.exists() and (dest / "cuda_l2_mi355x_F32F16F16F32_speedup_offline.csv").exists():

@@ -49,11 +49,11 @@ _COSTS = None
 
 
 def recorded_costs() -> dict:
-    """Seconds per shape as the round-4 whole-grid sweep recorded them (tools/sweep_costs_r04.json: time-boxed loop + autotune
+    """Seconds per shape as the round-6 whole-grid sweep recorded them (tools/sweep_costs_r06.json; rounds 4-5: sweep_costs_r04.json: time-boxed loop + autotune
     search of the in-process driver)."""
     global _COSTS
     if _COSTS is None:
-        path = PKG_DIR / "tools" / "sweep_costs_r04.json"
+        path = PKG_DIR / "tools" / "sweep_costs_r06.json"
         _COSTS = json.loads(path.read_text())["costs"] if path.exists() else {}
     return _COSTS
 

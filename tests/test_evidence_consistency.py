@@ -1,5 +1,6 @@
 """The figures DESIGN.md / README.md quote are recomputed here from the committed evidence files, so a number cannot drift away
 from its file (CPU only: nothing here touches a GPU, the oracle or the reference)."""
+import collections
 import csv
 import io
 import json
@@ -394,3 +395,101 @@ def test_round5_off_grid_traffic_and_parity_records():
     for mnk in ("64_4096_64", "512_4096_4096", "4096_4096_4096"):
         dk = json.loads((REPO / "profiles" / f"r05_pmc_{mnk}.json").read_text())["dominant_kernel"]
         assert dk["mnk"] == mnk and abs(dk["hbm_bytes_per_launch"] - rows[mnk]["hbm_bytes_per_launch"]) < 1
+
+
+# ---- round 6 -------------------------------------------------------------------------------------------------------------------------
+def _r6_figures():
+    sys.path.insert(0, str(PKG / "tools" / "lab"))
+    import design_round6_figures
+
+    return design_round6_figures.figures()
+
+
+def test_round6_figures_in_design_and_readme_are_recomputed_from_the_records():
+    """Every number of DESIGN.md's round-6 texts (lead paragraph, section 1.3, section 6.8) and of README.md's round-6 list is produced by
+    tools/lab/design_round6_figures.py from the committed records; here the same module recomputes them and they must be in the texts."""
+    f = _r6_figures()
+    d, readme = _design(), (REPO / "README.md").read_text()
+    in_design = ["BENCH_VALUE", "BENCH_FRAC", "PROF_AVG_US", "PROF_FRAC", "BENCH_RATIO", "GRID_ISO", "GRID_B2B", "GRID_ISO_MEAN", "GRID_B2B_MEAN", "REV_ISO_PCT", "REV_B2B_PCT",
+                 "SW_FP32_OFF", "SW_FP16_OFF", "SW_FP32_SRV", "SW_FP16_SRV", "C4_ROW_10", "C4_ROW_100", "C4_ROW_1000", "OFF_ISO", "OFF_B2B", "CLS_COMPUTE", "CLS_SMALLK", "CLS_SKINNY",
+                 "CLS_TINY", "CLS_MID", "RANDN_WORST", "C4_BENCH_US", "GRID_ISO_DEC", "GRID_B2B_DEC", "SW_DEC", "FAM_Q", "N_FUSED", "N_TWOPASS"]
+    for k in in_design:
+        assert f[k] in d, (k, f[k])
+    for k in ("BENCH_VALUE", "PROF_FRAC", "GRID_ISO", "GRID_B2B", "SW_FP32_OFF", "SW_FP16_OFF", "SW_FP32_SRV", "SW_FP16_SRV", "C4_ROW_100", "CLS_COMPUTE", "CLS_TINY", "RANDN_WORST"):
+        assert f[k] in readme, (k, f[k])
+
+
+def test_round6_records_describe_the_shipped_table():
+    shipped = _shipped()
+    rep = _recs(PKG / "tuning" / "r06_grid_plan_report_autotune_interleaved_mi355x.jsonl")
+    assert len(rep) == 1000 and len({r["mnk"] for r in rep}) == 1000
+    for r in rep:
+        assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]      # the shipped plans, nothing else
+        assert len(r["candidates"]) == 1 and r["stream_us"] > 0 and r["protocol"]["interleaved"] == 1 and r["protocol"]["reverse"] == 0
+        assert r["protocol"]["autotune_from_cache"] == [1, 1]                                                       # nothing was searched inside the run
+    rev = _recs(PKG / "tuning" / "r06_grid_1e11_up_plan_report_autotune_interleaved_reversed_mi355x.jsonl")
+    assert len(rev) >= 150 and all(r["protocol"]["reverse"] == 1 and 2.0 * math.prod(map(int, r["mnk"].split("_"))) >= 1e11 for r in rev)
+    for r in rev:
+        assert (r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]], r["mnk"]
+    # bench record + rocprofv3 stats of the same command
+    b = json.loads((REPO / "profiles" / "r06_bench.json").read_text())
+    prof = json.loads((REPO / "profiles" / "r06_bench_py_profiled_run.json").read_text())
+    assert b["metric"] == "HGEMM TFLOP/s" and b["n_gpus"] == 1 and b["dtype"] == "f16" and b["vs_baseline"] is None and "cpu_baseline" in b
+    assert prof["config"]["plan"] == b["config"]["plan"] and prof["steps"] == b["steps"] and prof["config"]["batch"] == b["config"]["batch"]
+    plan = b["config"]["plan"]
+    assert (plan["config"], plan["group_m"]) == (shipped["4096_4096_4096"][0], shipped["4096_4096_4096"][2])
+    rows = list(csv.DictReader(io.StringIO((REPO / "profiles" / "r06_bench_py_kernel_stats.csv").read_text())))
+    top = max(rows, key=lambda r: float(r["Percentage"]))
+    assert "hgemm_tn_sq_kernel" in top["Name"] and "CfgSQ<256, 256" in top["Name"] and float(top["Percentage"]) > 99.9
+    assert int(top["Calls"]) == (prof["steps"] + prof["warmup"]) * prof["config"]["batch"]
+    assert 0.93 < float(top["AverageNs"]) * 1e-3 / prof["roofline"]["launch_us"] < 1.01
+    import bench
+
+    t, src = bench.measured_traffic("4096_4096_4096")
+    assert src == "profiles/r06_pmc_4096_4096_4096.json" and abs(t / (3 * 2 * 4096 ** 2) - 2.34) < 0.03
+    # the closing check names every shipped geometry
+    log = (REPO / "profiles" / "r06_check_final.log").read_text()
+    assert re.search(r"check: \d+ runs, 0 failures", log)
+    named = set(re.search(r"^check-configs:(.*)$", log, re.M).group(1).split())
+    assert {c for c, _, _ in shipped.values()} <= named
+    # three table updates, each stability-gated: the recorded row changes
+    n = [len(_recs(PKG / "tuning" / name)) for name in R06_TABLE_UPDATES]
+    assert n == [106, 88, 115] and len({c["mnk"] for name in R06_TABLE_UPDATES for c in _recs(PKG / "tuning" / name)}) == 262
+    d = _design()
+    assert "106 rows" in d and "88 rows" in d and "115 rows" in d and "262" in d
+
+
+def test_round6_sweeps_use_the_cached_real_autotune_and_the_readme_is_generated():
+    import sweep_readme_r06
+
+    root = PKG / "eval_results" / "r06_sweep"
+    assert (root / "README.md").read_text() == sweep_readme_r06.build(root)
+    for acc in ("fp32", "fp16"):
+        for mode in ("offline", "server"):
+            recs = _recs(root / "records" / f"{acc}_{mode}_rank0.jsonl")
+            assert len(recs) == 1000 and len({r["mnk"] for r in recs}) == 1000
+            assert all(r["autotune_ok"] and r["autotune_budget_s"] == 1.0 for r in recs)                     # the real search: 1 s per layout
+            assert all(r["autotune"]["tn"]["candidates"] >= 4 for r in recs)
+            m = json.loads((root / f"merge_{acc}_{mode}.json").read_text())
+            assert m["shapes"] == 1000
+            col = [float(r["hipBLASLt-auto-tuning-max"]) for r in csv.DictReader(open(root / f"cuda_l2_mi355x_{'F32F16F16F32' if acc == 'fp32' else 'F16F16F16F16'}_speedup_{mode}.csv"))]
+            assert abs(_gm(col) - m["geomean_speedup_vs_hipBLASLt-auto-tuning-max"]) < 2e-3
+    # BASELINE config 4: three request rates, >= 1000 samples of cuda_l2 each, p50 <= p99
+    for q in (10, 100, 1000):
+        r = _recs(root / "config4" / f"qps_{q}.jsonl")[-1]
+        lat = r["latency_ms"]["cuda_l2_mi355x_fp32"]
+        assert r["mnk"] == "512_4096_4096" and r["target_qps"] == q and r["rounds"] * 7 >= 1000 and 0 < lat["p50"] <= lat["p99"]
+    # the cache file: one record per (layout, shape) and hipBLASLt build, every grid shape present for both builds
+    lines = [ln.split() for ln in (PKG / "tuning" / "r06_hipblaslt_autotune_cache.txt").read_text().splitlines() if ln and not ln.startswith("#")]
+    keys = collections.Counter((ln[0], ln[1], ln[2], ln[3]) for ln in lines)
+    assert len(keys) == 2000 and set(keys.values()) == {2} and all(float(ln[10]) == 1.0 for ln in lines)
+
+
+def test_round6_energy_table_and_withdrawn_experiments_are_on_file():
+    pw = json.loads((REPO / "profiles" / "r06_power_table.json").read_text())
+    assert set(pw["summary"]) == {"4096_4096_4096", "8192_8192_8192", "16384_16384_16384"}
+    for r in pw["rows"]:
+        assert r["reads"] == 2 and r["socket_w"] > 300 and r["gfx_mhz"] > 800 and abs(r["joule_per_tflop"] - r["socket_w"] * r["us"] * 1e-6 / (2.0 * math.prod(map(int, r["mnk"].split("_"))) * 1e-12)) < 0.02
+    assert (REPO / "profiles" / "withdrawn" / "r06_cuphase_first_look_mi355x.jsonl").exists()
+    d = _design()
+    assert "HGEMM_PLAN_CU_PHASE" in d and "fill-bound" in d
