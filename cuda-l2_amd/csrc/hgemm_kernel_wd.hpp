@@ -11,8 +11,8 @@
 //     global_load_dwordx4 per fragment from a K-contiguous row, 16 rows x 64 contiguous bytes per wave instruction;
 //   * KW = 1: the four waves of a workgroup form a 2 x 2 grid of wave tiles.  Nothing is shared between waves: no LDS,
 //     no barrier; a K of 64 is two MFMA slices behind one round trip to memory;
-//   * KW = 4 (round 6: also 8, 16): the waves share ONE wave tile and take the K = 32 slices round-robin (slice s -> wave s mod KW), four
-//     (round 5: up to sixteen) slices in flight per wave; their partials meet in LDS (one barrier) and the tile's quads are dealt out to the waves
+//   * KW = 4: the four waves share ONE wave tile and take the K = 32 slices round-robin (slice s -> wave s mod 4), four
+//     slices in flight per wave; their partials meet in LDS (one barrier) and the tile's quads are dealt out to the waves
 //     for the epilogue.  Together with split-K across workgroups this is how a 64 x 64 x 4096 problem reaches all CUs;
 //   * rows past the M / N edge are clamped on load (never stored); K must be a multiple of 32 per split;
 //   * epilogues: fp16 C, fp32 slabs for the two-pass combine, single-launch split-K (own compact slab layout: quad x of
@@ -23,23 +23,17 @@
 
 namespace hgemm_mi355x {
 
-// Round 6: KW = 8 / 16 ("_k8", "_k16") -- eight / sixteen waves (512 / 1024 threads) share one wave tile's K walk.  The tiny-output /
-// long-K class is a chain of memory round trips: with four waves a 1024 x 256 x 2048 problem needs split-K across workgroups to keep K in
-// flight, and the single-launch combine costs acknowledge + vote + reload behind the K loop (~4 us: every t / w variant of that shape lands
-// at 8.7 - 9.3 us back to back against hipBLASLt's 6.9).  Sixteen waves hold K = 128 .. 512 per wave in flight in ONE
-// round trip and meet in LDS (one barrier, KW x NQUAD KiB of partials) -- the in-workgroup counterpart of split-K, with no slab round trip.
 template <int FM_, int FN_, int KW_>
 struct CfgWD {
   static constexpr int FM = FM_, FN = FN_, KW = KW_;
-  static constexpr int NW = KW == 1 ? 4 : KW, THREADS = 64 * NW;
+  static constexpr int NW = 4, THREADS = 256;
   static constexpr int WM = KW == 1 ? 2 : 1, WN = KW == 1 ? 2 : 1;     // wave grid of the workgroup tile
   static constexpr int TM = FM * 16, TN = FN * 16;                      // wave tile
   static constexpr int BM = WM * TM, BN = WN * TN;                      // workgroup tile
   static constexpr int NQUAD = FM * FN;                                 // f32x4 accumulator quads per lane
   static constexpr int LDS_BYTES = KW == 1 ? 64 : KW * NQUAD * 64 * 16 + 64;   // KW partial tiles + the vote word
-  static_assert(KW == 1 || KW == 4 || KW == 8 || KW == 16, "K walk by one wave, or shared by 4 / 8 / 16");
+  static_assert(KW == 1 || KW == 4, "K walk by one wave or by all four");
   static_assert(FM * FN <= 16, "accumulators + one unrolled trip of fragments (at most 32 x 4 registers) stay below 256 registers");
-  static_assert(LDS_BYTES <= 160 * 1024, "the partial tiles of all waves meet in LDS");
 };
 
 template <class CFG, int EPI>
@@ -102,20 +96,14 @@ __global__ void __launch_bounds__(CFG::THREADS) hgemm_tn_wd_kernel(const GemmArg
   // flight: 16 slices for a 16 x 16 wave tile (K = 512 per wave and round trip, 2048 per `_k4` workgroup), 8 for 32 x 32 / 16 x 32.
   // With four slices a 64 x 64 x 4096 walk was 8 dependent round trips per wave (or a 4-way split-K and a second, serial
   // combine phase); hipBLASLt's MT16x16x512 kernels on these shapes have 512 of K in flight per wave.
-  // (sixteen waves = four per SIMD = 128 registers each: half the loads in flight per wave, the workgroup as a whole holds twice as many)
-  constexpr int LOADS = CFG::NW > 8 ? 16 : 32;
-  constexpr int UMAX = LOADS / (FM + FN) >= 16 ? 16 : LOADS / (FM + FN) >= 8 ? 8 : LOADS / (FM + FN) >= 4 ? 4 : 2;
+  constexpr int UMAX = 32 / (FM + FN) >= 16 ? 16 : 32 / (FM + FN) >= 8 ? 8 : 4;
   if constexpr (UMAX >= 16) {
     while (s + 15 * KW < nslices) trip(std::integral_constant<int, 16>{});
   }
   if constexpr (UMAX >= 8) {
     while (s + 7 * KW < nslices) trip(std::integral_constant<int, 8>{});
   }
-  if constexpr (UMAX >= 4) {
-    while (s + 3 * KW < nslices) trip(std::integral_constant<int, 4>{});
-  } else {
-    while (s + KW < nslices) trip(std::integral_constant<int, 2>{});
-  }
+  while (s + 3 * KW < nslices) trip(std::integral_constant<int, 4>{});
   if (s + KW < nslices) trip(std::integral_constant<int, 2>{});
   if (s < nslices) trip(std::integral_constant<int, 1>{});
 

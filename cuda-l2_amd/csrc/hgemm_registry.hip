@@ -38,10 +38,7 @@ constexpr int sk_residency(int lds_bytes, int nw, int acc_regs) {
 template <int BM, int BN, int KW>
 const char* wd_name() {
   static char buf[24];
-  if (!buf[0]) {
-    if (KW == 1) snprintf(buf, sizeof buf, "w%dx%d", BM, BN);
-    else snprintf(buf, sizeof buf, "w%dx%d_k%d", BM, BN, KW);
-  }
+  if (!buf[0]) snprintf(buf, sizeof buf, "w%dx%d%s", BM, BN, KW == 4 ? "_k4" : "");
   return buf;
 }
 #define HGEMM_STR2(x) #x
