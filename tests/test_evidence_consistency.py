@@ -287,7 +287,10 @@ def test_round5_bench_record_and_its_rocprof_stats_match_the_design_text():
     import bench
 
     t, src = bench.measured_traffic("4096_4096_4096")
-    assert src == "profiles/r05_pmc_4096_4096_4096.json" and abs(t / (3 * 2 * 4096 ** 2) - 2.34) < 0.03
+    # (round 6's closing run took the counters again: bench.py now cites its record, the round-5 one stays on file)
+    assert src == "profiles/r06_pmc_4096_4096_4096.json" and abs(t / (3 * 2 * 4096 ** 2) - 2.34) < 0.03
+    r5 = json.loads((REPO / "profiles" / "r05_pmc_4096_4096_4096.json").read_text())["dominant_kernel"]
+    assert abs(r5["hbm_bytes_per_launch"] / (3 * 2 * 4096 ** 2) - 2.34) < 0.03
 
 
 def test_round5_north_star_report_matches_design_and_readme():
@@ -310,7 +313,7 @@ def test_round5_north_star_report_matches_design_and_readme():
     iso, b2b = out["vs_strongest_hipblaslt_isolated"], out["vs_strongest_hipblaslt_back_to_back"]
     assert iso["shapes"] == len(rep) and b2b["shapes"] >= len(rep) - 5
     for blk in (iso, b2b):
-        assert f"{blk['geomean_speedup']:.3f}" in d and f"{blk['geomean_speedup']:.3f}" in readme
+        assert f"{blk['geomean_speedup']:.3f}" in d            # (README.md leads with round 6's figures since round 6; round 5's stay in DESIGN section 6.7)
         assert f"{blk['aggregate_tflops_ours']:.0f} vs {blk['aggregate_tflops_hipblaslt_strongest']:.0f} TFLOP/s" in d
         for dec in ("10", "11", "12"):
             if dec in {str(k) for k in blk["by_log10_flops"]}:
@@ -352,7 +355,7 @@ def test_round5_off_grid_traffic_and_parity_records():
         recs = _recs(PKG / "tuning" / name)
         assert len(recs) == 160 and all(r["pass"] for r in recs), name
     cand = [len(_recs(PKG / "tuning" / f"r05_candidate_parity_pass{i}.jsonl")) for i in (1, 2, 3, 4)]
-    assert " + ".join(map(str, cand)) + f" = {sum(cand)} candidate checks" in d and f"{sum(cand)} candidate checks" in (REPO / "README.md").read_text()
+    assert " + ".join(map(str, cand)) + f" = {sum(cand)} candidate checks" in d
     changed = set()
     for i, n in zip((1, 2, 3, 4), (182, 163, 28, 21)):
         ch = _recs(PKG / "tuning" / f"r05_retune_pass{i}_changes.jsonl")
