@@ -496,3 +496,13 @@ def test_round6_energy_table_and_withdrawn_experiments_are_on_file():
     assert (REPO / "profiles" / "withdrawn" / "r06_cuphase_first_look_mi355x.jsonl").exists()
     d = _design()
     assert "HGEMM_PLAN_CU_PHASE" in d and "fill-bound" in d
+
+
+def test_round6_insitu_demo_matches_the_design_text():
+    recs = _recs(REPO / "profiles" / "r06_insitu_selection_demo.jsonl")
+    assert len(recs) == 64 and all(r["choice"] in r["candidates"] for r in recs)
+    rep = [r for r in recs if not r["kept_the_table_plan"]]
+    d = _design()
+    assert f"keeps the table's plan on **{len(recs) - len(rep)}** and replaces **{len(rep)}**" in d
+    assert f"**+{(_gm(r['table_plan_us'] / r['chosen_plan_us'] for r in rep) - 1) * 100:.1f} %** faster" in d
+    assert not [r for r in rep if r["table_plan_us"] / r["chosen_plan_us"] < 0.97]
