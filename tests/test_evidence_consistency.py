@@ -506,3 +506,13 @@ def test_round6_insitu_demo_matches_the_design_text():
     assert f"keeps the table's plan on **{len(recs) - len(rep)}** and replaces **{len(rep)}**" in d
     assert f"**+{(_gm(r['table_plan_us'] / r['chosen_plan_us'] for r in rep) - 1) * 100:.1f} %** faster" in d
     assert not [r for r in rep if r["table_plan_us"] / r["chosen_plan_us"] < 0.97]
+
+
+def test_round6_process_flow_validation_matches_the_design_text():
+    root = PKG / "eval_results" / "r06_sweep"
+    col = lambda sub: {r["mnk"]: float(r["hipBLASLt-auto-tuning-max"]) for r in csv.DictReader(open(root / sub / "cuda_l2_mi355x_F32F16F16F32_speedup_offline.csv"))}
+    a, b = col("process_per_baseline"), col("inprocess_same_boxes")
+    assert len(a) == 10 and set(a) == set(b) and {"64_4096_64", "512_4096_4096", "4096_4096_4096"} <= set(a)
+    ga, gb = _gm(a.values()), _gm(b.values())
+    assert f"{ga:.3f} (processes) / {gb:.3f} (in-process), ratio {ga / gb:.3f}" in _design()
+    assert all(0.95 < a[m] / b[m] < 1.05 for m in a)
