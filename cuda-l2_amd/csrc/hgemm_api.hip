@@ -350,7 +350,14 @@ const TunedPlan* find_tuned(int M, int N, int K) {
   return nullptr;
 }
 
-bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
+// (round 6) every admissible corner plan with its modelled time, for the first-use selection off the grid: the runners-up of the
+// ranking below are the plans whose order the model is least sure about -- what the box should decide (13272 x 512 x 4440: the
+// model ranks q128x256 first, q256x256 at two splits measures 11 % faster)
+struct RankedPlan { double us; int cfg, splits, group_m; };
+bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m, RankedPlan* ranked = nullptr, int* n_ranked = nullptr) {
+  auto record = [&](double us, int c, int sp, int g) {
+    if (ranked && n_ranked && *n_ranked < 8) ranked[(*n_ranked)++] = RankedPlan{us, c, sp, g};
+  };
   int br[3][2];
   const int dims[3] = {M, N, K};
   for (int d = 0; d < 3; ++d) {
@@ -374,6 +381,7 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     const bool sk_usable = streamk_really_runs(e, M, N, K);   // (direct K tail, > 65536 tiles: the launch would run data-parallel)
     if ((p->splits & HGEMM_PLAN_STREAMK) && sk_usable) {
       const double t = model_us_streamk(e, M, N, K, streamk_grid(e, p->splits & HGEMM_SPLITK_MASK));
+      record(t, p->cfg, HGEMM_PLAN_STREAMK | (p->splits & HGEMM_SPLITK_MASK), default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn));
       if (t < best) {
         best = t; found = true;
         *cfg = p->cfg;
@@ -398,6 +406,12 @@ bool neighbour_plan(int M, int N, int K, int* cfg, int* splits, int* group_m) {
     if (e.name[0] == 't' && e.wm * e.wn == 8 && e.bm * e.bn <= 128 * 64 &&
         (long)((M + e.bm - 1) / e.bm) * ((N + e.bn - 1) / e.bn) * s > 2L * kCUs) continue;
     const double t = model_us(e, M, N, K, s);
+    {
+      int sp = s > 1 ? (s | (p->splits & HGEMM_SPLITK_FUSED)) : 1;
+      if (e.name[0] == 'r' && K % 64 == 0) sp |= p->splits & (HGEMM_PLAN_RS_XCD_STAGGER | HGEMM_PLAN_RS_NT_LOADS);
+      if (e.name[0] == 'q') sp |= p->splits & (HGEMM_PLAN_XCD_STAGGER | HGEMM_PLAN_PHASE_OFFSET | HGEMM_PLAN_PHASE_OFFSET4);
+      record(t, p->cfg, sp, default_group_m(e, (M + e.bm - 1) / e.bm, (N + e.bn - 1) / e.bn));
+    }
     if (t < best) {
       best = t; found = true;
       *cfg = p->cfg;
@@ -555,6 +569,17 @@ int insitu_candidates(int M, int N, int K, PlanTriple out[3]) {
   };
   for (const AltRow* r = g_alt_rows; r->cfg; ++r)
     if (r->M == M && r->N == N && r->K == K) add({hgemm_mi355x_config_by_name(r->cfg), r->splits, r->group_m});
+  // off the grid (round 6): the runners-up among the tuned plans of the surrounding grid shapes, in the model's order -- every one of
+  // them an oracle-verified plan of its own corner, run here through the same edge predication / K tail as the planner's choice
+  std::call_once(g_tuned_once, build_tuned_index);
+  if (p0.cfg >= 0 && !find_tuned(M, N, K) && K % 8 == 0 && (N & 3) == 0) {
+    RankedPlan ranked[8];
+    int nr = 0, c0, s0, g0;
+    if (neighbour_plan(M, N, K, &c0, &s0, &g0, ranked, &nr)) {
+      std::sort(ranked, ranked + nr, [](const RankedPlan& a, const RankedPlan& b) { return a.us < b.us; });
+      for (int i = 0; i < nr; ++i) add({ranked[i].cfg, ranked[i].splits, ranked[i].group_m});
+    }
+  }
   if (p0.cfg >= 0 && !(p0.splits & HGEMM_PLAN_STREAMK)) {
     const KernelEntry& e = g_kernel_table[p0.cfg];
     if (e.name[0] == 'q' && e.mi == 16 && K % e.kgran == 0) {

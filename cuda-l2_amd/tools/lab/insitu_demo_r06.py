@@ -1,7 +1,7 @@
 """Round 6: what the first-use selection (HGEMM_MI355X_INSITU / hgemm_mi355x_set_insitu) does on THIS box for the part of the table that moves with the box
 (DESIGN.md section 6.8): 64 rows -- every 4th skinny row, every 4th mid-class row with K >= 4096, the ten rows of round 5's demo -- each at the table's plan
 (selection off) and after the selection (on), three interleaved repetitions of six launches, median of the medians.
-    python cuda-l2_amd/tools/lab/insitu_demo_r06.py > gpurun_out/insitu_demo_r06.jsonl"""
+    python cuda-l2_amd/tools/lab/insitu_demo_r06.py [SHAPES.txt] > gpurun_out/insitu_demo_r06.jsonl"""
 import ctypes
 import json
 import re
@@ -46,7 +46,13 @@ def call_us(a, b, bt, c, m, n, k, reps=6):
     return sorted(ts)[len(ts) // 2]
 
 
-for mnk in shapes():
+def shape_list():
+    if len(sys.argv) > 1:      # a shape file (e.g. tools/offgrid_shapes.txt: off the grid the candidates are the runners-up among the corner plans)
+        return [ln.strip() for ln in open(sys.argv[1]) if ln.strip() and not ln.startswith("#")]
+    return shapes()
+
+
+for mnk in shape_list():
     m, n, k = map(int, mnk.split("_"))
     a = torch.randn(m, k, dtype=torch.half, device="cuda"); b = torch.randn(k, n, dtype=torch.half, device="cuda"); bt = b.t().contiguous()
     c = torch.empty(m, n, dtype=torch.half, device="cuda")

@@ -146,7 +146,8 @@ int hgemm_mi355x_launch(int config_id, int splits, int group_m,
  * invocation, kernels/h100_F32F16F16F32/64_4096_64.cu:623-690).  Off by default: the entry points take the tuned table's plan.
  * With HGEMM_MI355X_INSITU=1 in the environment, or after hgemm_mi355x_set_insitu(1) (returns the previous setting; 0 also
  * forgets every recorded choice), the FIRST call of hgemm_mi355x_fp32 / _fp16 for a shape times up to three oracle-verified
- * plans -- the table's and its alternates (hgemm_mi355x_insitu_candidates lists them, the table's plan first) -- on the call's
+ * plans -- the table's and its alternates (hgemm_mi355x_insitu_candidates lists them, the table's plan first; off the grid, round 6:
+ * the planner's plan, then the runners-up among the tuned plans of the surrounding grid shapes in the model's order) -- on the call's
  * own operands and stream (interleaved rounds), keeps the fastest for the (process, device) (an alternate must win by 3 %) and runs it; that call
  * synchronises the stream, so it belongs in a warm-up phase.  Later calls, and calls on a capturing stream, time nothing.
  * hgemm_mi355x_insitu_choice returns 1 and the recorded plan once a shape has been measured. */

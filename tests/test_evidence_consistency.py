@@ -516,3 +516,12 @@ def test_round6_process_flow_validation_matches_the_design_text():
     ga, gb = _gm(a.values()), _gm(b.values())
     assert f"{ga:.3f} (processes) / {gb:.3f} (in-process), ratio {ga / gb:.3f}" in _design()
     assert all(0.95 < a[m] / b[m] < 1.05 for m in a)
+
+
+def test_round6_offgrid_insitu_demo_matches_the_design_text():
+    recs = _recs(REPO / "profiles" / "r06_insitu_selection_demo_offgrid.jsonl")
+    assert len(recs) == 80 and all(r["choice"] in r["candidates"] and 1 <= len(r["candidates"]) <= 3 for r in recs)
+    rep = [r for r in recs if not r["kept_the_table_plan"]]
+    d = _design()
+    assert f"kept on **{len(recs) - len(rep)}**, replaced on **{len(rep)}**" in d
+    assert f"**+{(_gm(r['table_plan_us'] / r['chosen_plan_us'] for r in rep) - 1) * 100:.1f} %** faster re-timed interleaved" in d
