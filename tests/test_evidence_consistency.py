@@ -525,3 +525,15 @@ def test_round6_offgrid_insitu_demo_matches_the_design_text():
     d = _design()
     assert f"kept on **{len(recs) - len(rep)}**, replaced on **{len(rep)}**" in d
     assert f"**+{(_gm(r['table_plan_us'] / r['chosen_plan_us'] for r in rep) - 1) * 100:.1f} %** faster re-timed interleaved" in d
+
+
+def test_round6_second_box_report_matches_the_design_text():
+    sys.path.insert(0, str(PKG / "tools" / "lab"))
+    import design_round6_figures as F
+
+    rep = _recs(PKG / "tuning" / "r06_grid_plan_report_autotune_interleaved_second_box_mi355x.jsonl")
+    shipped = _shipped()
+    assert len(rep) == 1000 and all((r["best"]["config"], r["best"]["splits"], r["best"]["group_m"]) == shipped[r["mnk"]] and r["protocol"]["interleaved"] == 1 for r in rep)
+    iso, b2b = F.ratios(rep)
+    d = _design()
+    assert f"back to back **{_gm(b2b):.3f}** ({sum(x > 1 for x in b2b)} faster" in d and f"isolated **{_gm(iso):.3f}** ({sum(x > 1 for x in iso)} faster)" in d
